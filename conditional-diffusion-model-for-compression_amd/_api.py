@@ -1,0 +1,10 @@
+"""Public surface of the package (re-exported by the `cdx` import shim)."""
+from .config import unet_config, validate_unet_config, named_config, UNET_DEFAULTS, SCHEDULE_DEFAULTS
+from .schedule import make_schedule, timestep_subsequence, step_coefficients, StepCoef
+from .graph import build_graph
+from .params import init_params, synthetic_batch
+from . import rng
+
+__all__ = ["unet_config", "validate_unet_config", "named_config", "UNET_DEFAULTS", "SCHEDULE_DEFAULTS",
+           "make_schedule", "timestep_subsequence", "step_coefficients", "StepCoef",
+           "build_graph", "init_params", "synthetic_batch", "rng"]

@@ -1,0 +1,70 @@
+"""Seeded synthetic weights and inputs (SURVEY.md section 8d "synthetic inputs").
+
+No checkpoint format exists in the reference (snapshot is empty), so weights are a
+deterministic, library-version-independent function of (cfg, seed): fan-in-scaled
+uniform for conv / linear weights and biases (PyTorch-default-like bound 1/sqrt(fan_in)),
+GroupNorm gamma = 1, beta = 0 (optionally jittered for tests).  Arrays use torch layouts
+(conv OIHW, linear [out, in]) so the same dict feeds the oracle and the HIP backend.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import rng
+from .graph import build_graph
+
+
+def init_params(cfg: dict, seed: int = 0, affine_jitter: float = 0.0) -> dict:
+    g = build_graph(cfg)
+    params = {}
+    for pidx, (name, shape) in enumerate(g.param_shapes.items()):
+        n = int(np.prod(shape))
+        key = rng.stream_key(seed, rng.PARAM_A + pidx, 0)
+        is_norm = ".norm" in name
+        if is_norm:
+            base = 1.0 if name.endswith(".weight") else 0.0
+            if affine_jitter:
+                v = base + affine_jitter * (2.0 * rng.uniform(key, n) - 1.0)
+            else:
+                v = np.full(n, base)
+        else:
+            if name.endswith(".weight"):
+                fan_in = int(np.prod(shape[1:]))
+            else:   # bias: fan_in of the matching weight
+                fan_in = int(np.prod(g.param_shapes[name[:-5] + ".weight"][1:]))
+            bound = 1.0 / math.sqrt(fan_in)
+            v = (2.0 * rng.uniform(key, n) - 1.0) * bound
+        params[name] = v.astype(np.float32).reshape(shape)
+    return params
+
+
+def synthetic_batch(cfg: dict, seed: int, first_image: int, count: int) -> dict:
+    """Synthetic target / cond for images [first_image, first_image+count) of a run.
+
+    target [count,3,H,W] ~ U(-1,1);  concat mode: cond [count,Cc,H/16,W/16] =
+    avgpool16(target)[:Cc] + 0.1 N(0,1);  cross_attn mode: cond [count,L,D] ~ N(0,1),
+    L = (H/16)^2.  Keyed by GLOBAL image index so results do not depend on sharding.
+    """
+    H = cfg["image_size"]
+    C = cfg["in_channels"]
+    tgt = np.empty((count, C, H, H), np.float32)
+    conds = []
+    hc = max(H // 16, 1)
+    for k in range(count):
+        i = first_image + k
+        u = rng.uniform(rng.stream_key(seed, i, rng.STREAM_TARGET), C * H * H)
+        tgt[k] = (2.0 * u - 1.0).astype(np.float32).reshape(C, H, H)
+        ck = rng.stream_key(seed, i, rng.STREAM_COND)
+        if cfg["cond_mode"] == "concat":
+            cc = cfg["cond_channels"]
+            f = H // hc
+            pooled = tgt[k].reshape(C, hc, f, hc, f).mean(axis=(2, 4), dtype=np.float64)
+            pooled = np.resize(pooled, (cc, hc, hc)) if cc != C else pooled
+            noise = rng.normal(ck, cc * hc * hc).reshape(cc, hc, hc)
+            conds.append((pooled + 0.1 * noise).astype(np.float32))
+        else:
+            L, D = hc * hc, cfg["context_dim"]
+            conds.append(rng.normal(ck, L * D).reshape(L, D))
+    return dict(target=tgt, cond=np.stack(conds))
