@@ -1,0 +1,158 @@
+"""ctypes binding of libcdx.so (include/cdx.h).  The ONLY module that touches the C ABI.
+
+There is no CPU fallback: if the shared library is missing or an entry point is absent the
+import of the HIP backend fails loudly (RuntimeError), as the product path must.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcdx.so")
+
+ABI_VERSION = 1
+CONV_UPSAMPLE2X, CONV_GN, CONV_SILU = 1, 2, 4
+LINEAR_SILU_IN = 1
+CONV_KC = 32
+
+_f = C.c_void_p   # device / host pointers are passed as raw addresses
+_i = C.c_int32
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("src0", _f), ("src1", _f), ("c0", _i), ("c1", _i),
+                ("batch", _i), ("hin", _i), ("win", _i), ("hout", _i), ("wout", _i),
+                ("cout", _i), ("ksize", _i), ("stride", _i), ("flags", _i),
+                ("wpacked", _f), ("bias", _f), ("gn_scale", _f), ("gn_shift", _f),
+                ("temb", _f), ("temb_ld", _i), ("residual", _f), ("out", _f), ("out_ld", _i)]
+
+
+class GnStatsArgs(C.Structure):
+    _fields_ = [("src0", _f), ("src1", _f), ("c0", _i), ("c1", _i), ("batch", _i), ("hw", _i),
+                ("groups", _i), ("eps", C.c_float), ("gamma", _f), ("beta", _f),
+                ("scale", _f), ("shift", _f), ("mean", _f), ("rstd", _f)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", _f), ("q_ld", _i), ("k", _f), ("k_ld", _i), ("v", _f), ("v_ld", _i),
+                ("batch", _i), ("nq", _i), ("nk", _i), ("heads", _i), ("head_dim", _i),
+                ("scale", C.c_float), ("out", _f), ("out_ld", _i)]
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [("x", _f), ("x_ld", _i), ("w", _f), ("bias", _f), ("m", _i), ("n", _i), ("k", _i),
+                ("flags", _i), ("out", _f), ("out_ld", _i)]
+
+
+class TimestepEmbeddingArgs(C.Structure):
+    _fields_ = [("t", _f), ("batch", _i), ("dim", _i), ("out", _f)]
+
+
+class DiffusionUpdateArgs(C.Structure):
+    _fields_ = [("x", _f), ("x_ld", _i), ("eps", _f), ("eps_ld", _i),
+                ("batch", _i), ("hw", _i), ("channels", _i),
+                ("ca", C.c_float), ("cb", C.c_float), ("cx", C.c_float), ("c0", C.c_float),
+                ("ce", C.c_float), ("sigma", C.c_float), ("clip_x0", _i),
+                ("seed", C.c_uint64), ("first_image", C.c_int64), ("noise_stream", _i)]
+
+
+class GaussFillArgs(C.Structure):
+    _fields_ = [("x", _f), ("x_ld", _i), ("batch", _i), ("hw", _i), ("channels", _i),
+                ("seed", C.c_uint64), ("first_image", C.c_int64), ("noise_stream", _i)]
+
+
+class CondEmbedArgs(C.Structure):
+    _fields_ = [("cond", _f), ("cc", _i), ("hc", _i), ("wc", _i), ("x", _f), ("x_ld", _i),
+                ("c_off", _i), ("batch", _i), ("h", _i), ("w", _i)]
+
+
+class ExportImageArgs(C.Structure):
+    _fields_ = [("x", _f), ("x_ld", _i), ("batch", _i), ("hw", _i), ("channels", _i),
+                ("lo", C.c_float), ("hi", C.c_float), ("out", _f)]
+
+
+# op name -> args struct; every op has cdx_<op>(args*, ws, ws_bytes, stream) and cdx_<op>_workspace(args*)
+OPS = {
+    "conv_f32": ConvArgs,
+    "gn_stats_f32": GnStatsArgs,
+    "attn_f32": AttnArgs,
+    "linear_f32": LinearArgs,
+    "timestep_embedding_f32": TimestepEmbeddingArgs,
+    "diffusion_update_f32": DiffusionUpdateArgs,
+    "gauss_fill_f32": GaussFillArgs,
+    "cond_embed_f32": CondEmbedArgs,
+    "export_image_f32": ExportImageArgs,
+}
+
+# every exported symbol include/cdx.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTS = (["cdx_abi_version", "cdx_strerror", "cdx_launch_count",
+            "cdx_conv_packed_floats", "cdx_conv_pack_weights_f32"]
+           + [f"cdx_{op}" for op in OPS] + [f"cdx_{op}_workspace" for op in OPS])
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libcdx.so once; raise if it is not built or its ABI version differs."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(or `make -C conditional-diffusion-model-for-compression_amd/csrc`). "
+                           "There is no CPU fallback for the HIP path.")
+    L = C.CDLL(LIB_PATH)
+    missing = [s for s in EXPORTS if not hasattr(L, s)]
+    if missing:
+        raise RuntimeError(f"libcdx.so lacks symbols {missing}")
+    L.cdx_abi_version.restype = C.c_int
+    if L.cdx_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libcdx.so ABI {L.cdx_abi_version()} != binding {ABI_VERSION}")
+    L.cdx_strerror.restype = C.c_char_p
+    L.cdx_strerror.argtypes = [C.c_int]
+    L.cdx_launch_count.restype = C.c_uint64
+    L.cdx_conv_packed_floats.restype = C.c_size_t
+    L.cdx_conv_packed_floats.argtypes = [_i, _i, _i, _i]
+    L.cdx_conv_pack_weights_f32.restype = C.c_int
+    L.cdx_conv_pack_weights_f32.argtypes = [_f, _i, _i, _i, _i, _f]
+    for op, st in OPS.items():
+        fn = getattr(L, f"cdx_{op}")
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(st), C.c_void_p, C.c_size_t, C.c_void_p]
+        ws = getattr(L, f"cdx_{op}_workspace")
+        ws.restype = C.c_size_t
+        ws.argtypes = [C.POINTER(st)]
+    _lib = L
+    return L
+
+
+class CdxError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise CdxError(f"{what}: {lib().cdx_strerror(rc).decode()} (status {rc})")
+
+
+def call(op: str, args: C.Structure, ws_ptr: int, ws_bytes: int, stream: int) -> None:
+    check(getattr(lib(), f"cdx_{op}")(C.byref(args), ws_ptr, ws_bytes, stream), f"cdx_{op}")
+
+
+def workspace_bytes(op: str, args: C.Structure) -> int:
+    return int(getattr(lib(), f"cdx_{op}_workspace")(C.byref(args)))
+
+
+def pack_conv_weights(w_oihw, c0: int, c1: int):
+    """numpy OIHW float32 -> numpy packed float32 image (host)."""
+    import numpy as np
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    cout, cin, k, _ = w.shape
+    assert cin == c0 + c1
+    n = int(lib().cdx_conv_packed_floats(c0, c1, cout, k))
+    if n == 0:
+        raise CdxError("cdx_conv_packed_floats: bad arguments")
+    out = np.empty(n, np.float32)
+    check(lib().cdx_conv_pack_weights_f32(w.ctypes.data, c0, c1, cout, k, out.ctypes.data), "cdx_conv_pack_weights_f32")
+    return out

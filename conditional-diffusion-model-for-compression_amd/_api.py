@@ -8,3 +8,8 @@ from . import rng
 __all__ = ["unet_config", "validate_unet_config", "named_config", "UNET_DEFAULTS", "SCHEDULE_DEFAULTS",
            "make_schedule", "timestep_subsequence", "step_coefficients", "StepCoef",
            "build_graph", "init_params", "synthetic_batch", "rng"]
+from .unet import UNet
+from .sampler import Sampler, sample
+from . import ops, _abi
+
+__all__ += ["UNet", "Sampler", "sample", "ops", "_abi"]

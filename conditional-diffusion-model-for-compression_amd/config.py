@@ -53,12 +53,15 @@ def validate_unet_config(cfg: dict) -> dict:
     nlev = len(cfg["channel_mult"])
     if cfg["image_size"] % (1 << (nlev - 1)):
         raise ValueError("image_size must be divisible by 2**(levels-1)")
-    for m in cfg["channel_mult"]:
+    res = cfg["image_size"]
+    for lvl, m in enumerate(cfg["channel_mult"]):
         c = ch * m
         if c % g:
             raise ValueError(f"channels {c} not divisible by groups {g}")
-        if c % cfg["head_dim"] and (cfg["attn_resolutions"] or cfg["cross_attn_resolutions"]):
-            raise ValueError(f"channels {c} not divisible by head_dim {cfg['head_dim']}")
+        has_attn = (res in cfg["attn_resolutions"] or res in cfg["cross_attn_resolutions"] or lvl == nlev - 1)
+        if has_attn and c % cfg["head_dim"]:
+            raise ValueError(f"channels {c} (resolution {res}) not divisible by head_dim {cfg['head_dim']}")
+        res //= 2
     if cfg["cond_mode"] == "cross_attn":
         cfg["cond_channels"] = 0
     return cfg

@@ -1,0 +1,21 @@
+// Instantiations of the implicit-GEMM convolution: ksize=1 stride=1.
+#include "conv_kernel.h"
+namespace cdx {
+#define CDX_CONV_CASES(KS, ST) \
+    CDX_CONV_CASE(KS, ST, 2, 0, 1, 4, 4) \
+    CDX_CONV_CASE(KS, ST, 2, 1, 2, 2, 2) \
+    CDX_CONV_CASE(KS, ST, 2, 2, 4, 1, 1) \
+    CDX_CONV_CASE(KS, ST, 3, 0, 1, 4, 4) \
+    CDX_CONV_CASE(KS, ST, 3, 1, 2, 2, 2) \
+    CDX_CONV_CASE(KS, ST, 3, 2, 4, 1, 1) \
+    CDX_CONV_CASE(KS, ST, 4, 0, 1, 4, 4) \
+    CDX_CONV_CASE(KS, ST, 4, 1, 2, 2, 2) \
+    CDX_CONV_CASE(KS, ST, 4, 2, 4, 1, 1) \
+    CDX_CONV_CASE(KS, ST, 5, 0, 1, 4, 4) \
+    CDX_CONV_CASE(KS, ST, 5, 1, 2, 2, 2) \
+    CDX_CONV_CASE(KS, ST, 5, 2, 4, 1, 1) \
+
+int conv_dispatch_k1s1(int logtw, int wcfg, const ConvParams& p, hipStream_t stream) {
+    CDX_CONV_DISPATCH_BODY(1, 1)
+}
+}  // namespace cdx

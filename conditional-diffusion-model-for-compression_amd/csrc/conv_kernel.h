@@ -1,0 +1,242 @@
+// Implicit-GEMM convolution on the gfx950 fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+// GEMM view: M = output pixels, N = cout, K = taps * cin.  One 256-thread workgroup (4 waves, one
+// per SIMD) owns a TH x TW rectangle of output pixels of one image (BM = TH*TW pixels) and BN output
+// channels.  Per 32-channel chunk of the input:
+//   1. the (TH-1)*S+KS by (TW-1)*S+KS input halo tile is gathered NHWC -> LDS ONCE, with
+//      GroupNorm scale/shift + SiLU, nearest-2x upsampling and channel concat applied on the way
+//      (coalesced 128-B reads per pixel; zero padding applied after the activation);
+//   2. all KS*KS taps read their A operand from that one LDS image at shifted addresses
+//      (ds_read_b128 with immediate offsets: 9x reuse of every staged byte);
+//   3. the B operand (weights) never touches LDS: the host pre-packs it so each lane's
+//      16-byte fragment for 4 consecutive MFMAs is one coalesced global_load_dwordx4 (L2-resident),
+//      prefetched one tap ahead.
+// K-order inside a chunk is permuted so that one 16-B fragment feeds 4 MFMAs: MFMA e of group s
+// consumes channel 8s + 4*(lane>>5) + e from both operands.
+//
+// LDS image: pixel stride PS = 36 floats (32 + 4 pad), row stride RS = multiple of 64 floats, which
+// makes every ds_read_b128 lane group hit 16 distinct 4-bank slots (conflict-free) for TW >= 16.
+#pragma once
+#include "common.h"
+
+namespace cdx {
+
+struct ConvParams {
+    const float* src[2];
+    int csrc[2];     // channels of each source
+    int nchunk0;     // chunks belonging to src0
+    int nchunks;     // total chunks
+    int ctot;        // c0 + c1 (row length of gn_scale / gn_shift)
+    int B, Hin, Win, Hout, Wout, Cout;
+    int ups, gn, silu;
+    const float* w;
+    const float* bias;
+    const float* gscale;
+    const float* gshift;
+    const float* temb;
+    int temb_ld;
+    const float* residual;
+    float* out;
+    int out_ld;
+    int tiles_x, tiles_y;
+};
+
+template <int KS_, int STRIDE_, int LOGTW_, int WM_, int WN_, int MT_>
+struct ConvCfg {
+    static constexpr int KS = KS_, STRIDE = STRIDE_, LOGTW = LOGTW_, WM = WM_, WN = WN_, MT = MT_;
+    static constexpr int KC = CDX_CONV_KC, PS = KC + 4;
+    static constexpr int TAPS = KS * KS, PAD = KS / 2;
+    static constexpr int TW = 1 << LOGTW;
+    static constexpr int BM = WM * MT * 32, BN = WN * 32;
+    static constexpr int TH = BM / TW;
+    static constexpr int RPM = 32 / TW;  // output rows per 32-pixel MFMA tile
+    static constexpr int HH = (TH - 1) * STRIDE + KS, HW = (TW - 1) * STRIDE + KS;
+    static constexpr int RS = ((HW * PS + 63) / 64) * 64;
+    static constexpr int LDS_FLOATS = HH * RS;
+    static constexpr int NPIX = HH * HW;
+    static constexpr int NPASS = (NPIX + 31) / 32;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(TW <= 32 && BM % TW == 0, "tile shape");
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+};
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
+    constexpr int KC = C::KC, PS = C::PS, RS = C::RS, TAPS = C::TAPS, MT = C::MT, NPASS = C::NPASS;
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / C::WN, wn = wave % C::WN;
+
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int b = bx / p.tiles_y;
+    const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+    const int iy0 = oy0 * C::STRIDE - C::PAD, ix0 = ox0 * C::STRIDE - C::PAD;
+    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+
+    // ---- loader geometry (chunk independent): thread -> (pixel slot pl, channel quad q) ----
+    const int q = tid & 7, pl = tid >> 3;
+    int soff[NPASS];        // source pixel index (b, sy, sx) flattened, or -1
+    unsigned vmask = 0;
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int hp = i * 32 + pl;
+        const int hy = hp / C::HW, hx = hp - hy * C::HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool ok = hp < C::NPIX && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+        soff[i] = ok ? ((b * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups)) : 0;
+        vmask |= ok ? (1u << i) : 0u;
+    }
+
+    f32x4 pre[NPASS];
+    f32x4 gsc, gsh;
+    bool cvalid;   // this thread's channel quad exists in the current source
+
+    auto issue_loads = [&](int chunk) {
+        const int s = chunk >= p.nchunk0;
+        const int cl = (s ? chunk - p.nchunk0 : chunk) * KC + q * 4;   // channel within source
+        const int cs = p.csrc[s];
+        cvalid = cl < cs;
+        // Loads are unconditional (padding / tail lanes read a safe in-bounds address and are zeroed
+        // at write time): a per-lane "load or zero" select would serialise the loads behind waits.
+        const float* __restrict__ base = p.src[s] + (cvalid ? cl : 0);
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i)
+            pre[i] = *reinterpret_cast<const f32x4*>(base + (size_t)soff[i] * cs);
+        if (p.gn) {
+            const int cg = cvalid ? (s ? p.csrc[0] : 0) + cl : 0;
+            gsc = *reinterpret_cast<const f32x4*>(p.gscale + (size_t)b * p.ctot + cg);
+            gsh = *reinterpret_cast<const f32x4*>(p.gshift + (size_t)b * p.ctot + cg);
+        }
+    };
+
+    auto write_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int hp = i * 32 + pl;
+            const int hy = hp / C::HW, hx = hp - hy * C::HW;
+            f32x4 v = pre[i];
+            const bool ok = cvalid && ((vmask >> i) & 1u);
+            if (p.gn) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], gsc[e], gsh[e]);
+            }
+            if (p.silu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+            }
+            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (hp < C::NPIX) *reinterpret_cast<f32x4*>(&lds[hy * RS + hx * PS + q * 4]) = v;
+        }
+    };
+
+    // ---- MFMA operand addressing ----
+    const int li = lane & 31, lh = lane >> 5;
+    const int p0 = wm * MT * 32 + li;                       // pixel of M-tile 0, row li
+    const int a_base = ((p0 >> C::LOGTW) * C::STRIDE) * RS + ((p0 & (C::TW - 1)) * C::STRIDE) * PS + lh * 4;
+    const int ntile = blockIdx.y * C::WN + wn;
+    const bool nvalid = ntile * 32 < p.Cout;                // wave-uniform
+    const float* __restrict__ wp =
+        p.w + ((size_t)(nvalid ? ntile : 0) * p.nchunks * TAPS) * 1024 + lane * 4;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // Weight fragments: one 16-B load per lane feeds 4 MFMAs x MT tiles (= one "group" of 16*MT/4
+    // MFMAs, >= 1024 cycles at MT = 4), so prefetching ONE group ahead covers an L2 / MALL hit.
+    // Groups are consecutive 1 KiB pieces of the packed image: index g = (chunk*TAPS + tap)*4 + s.
+    f32x4 bcur = *reinterpret_cast<const f32x4*>(wp);
+    size_t gidx = 0;
+
+    issue_loads(0);
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        write_lds();
+        __syncthreads();
+        if (chunk + 1 < p.nchunks) issue_loads(chunk + 1);
+        if (nvalid) {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int ky = tap / C::KS, kx = tap % C::KS;
+                // Opaque copy of the LDS base per tap: M-tile t at tap row ky and M-tile t+1 at row
+                // ky-1 alias when a tile is one image row; without this hipcc keeps the earlier
+                // fragments alive for reuse and spills them to scratch.
+                int ab = a_base;
+                asm volatile("" : "+v"(ab));
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    // the packed image carries a 4 KiB tail pad, so the read past the last group
+                    // stays inside the allocation
+                    ++gidx;
+                    const f32x4 bnxt = *reinterpret_cast<const f32x4*>(wp + gidx * 256);
+                    f32x4 a[MT];
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        a[t] = *reinterpret_cast<const f32x4*>(
+                            &lds[ab + (t * C::RPM * C::STRIDE + ky) * RS + kx * PS + s * 8]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int t = 0; t < MT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][e], bcur[e], acc[t], 0, 0, 0);
+                    bcur = bnxt;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[t][r] is out[pixel (r&3) + 8*(r>>2) + 4*lh of tile t][channel li] ----
+    if (!nvalid) return;
+    const int n = ntile * 32 + li;
+    if (n >= p.Cout) return;
+    float add = p.bias ? p.bias[n] : 0.f;
+    if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (wm * MT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int oy = oy0 + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
+            if (oy < p.Hout && ox < p.Wout) {
+                const size_t pix = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+                float v = acc[t][r] + add;
+                if (p.residual) v += p.residual[pix * p.Cout + n];
+                p.out[pix * p.out_ld + n] = v;
+            }
+        }
+    }
+}
+
+template <class C>
+inline int conv_launch(const ConvParams& p, hipStream_t stream) {
+    dim3 grid(p.tiles_x * p.tiles_y * p.B, ceil_div(p.Cout, C::BN));
+    hipLaunchKernelGGL(conv_kernel<C>, grid, dim3(256), 0, stream, p);
+    return check_launch();
+}
+
+// wave-layout ids used by the dispatcher
+enum { WCFG_1x4x4 = 0, WCFG_2x2x2 = 1, WCFG_4x1x1 = 2, WCFG_1x4x2 = 3, WCFG_2x2x1 = 4 };
+
+int conv_dispatch_k3s1(int logtw, int wcfg, const ConvParams& p, hipStream_t stream);
+int conv_dispatch_k1s1(int logtw, int wcfg, const ConvParams& p, hipStream_t stream);
+int conv_dispatch_k3s2(int logtw, int wcfg, const ConvParams& p, hipStream_t stream);
+
+#define CDX_CONV_DISPATCH_BODY(KS, ST)                                                         \
+    switch (wcfg * 8 + logtw) {                                                                \
+        CDX_CONV_CASES(KS, ST)                                                                 \
+        default: return CDX_ENOTSUP;                                                           \
+    }
+#define CDX_CONV_CASE(KS, ST, LT, W, WM, WN, MT) \
+    case (W) * 8 + (LT): return conv_launch<ConvCfg<KS, ST, LT, WM, WN, MT>>(p, stream);
+
+}  // namespace cdx

@@ -1,0 +1,144 @@
+// U2: GroupNorm statistics -> per-(batch, channel) scale / shift, consumed by the convolution's
+// tile gather (so GroupNorm+SiLU never makes its own HBM round trip).
+//
+// Two HBM-bound kernels, no atomics, fixed summation order (bitwise reproducible, and independent of
+// the batch size: the pixel split depends on hw only, so an image's statistics do not change with
+// sharding):
+//   gn_partial : grid (nsplit, batch); each workgroup sums x and x^2 per channel over its pixel
+//                range, float4 loads, float64 accumulators -> partial[b][split][c][2]
+//   gn_finalize: one wave per (batch, group): sums the partials in float64, mean / rstd, then
+//                scale = rstd*gamma, shift = beta - mean*scale in float32 (F.group_norm's own form).
+// No reference file exists to cite (reference snapshot is empty); semantics = torch F.group_norm.
+#include "common.h"
+
+using namespace cdx;
+
+namespace {
+
+constexpr int kPixelsPerSplit = 256;
+
+__host__ __device__ inline int gn_nsplit(int hw) {
+    int n = hw / kPixelsPerSplit;
+    return n < 1 ? 1 : (n > 1024 ? 1024 : n);
+}
+
+__global__ __launch_bounds__(256) void gn_partial(const float* __restrict__ src, int C, int hw, int nsplit,
+                                                  double* __restrict__ part, int coff, int ctot) {
+    __shared__ double red[256 * 8];
+    const int tid = threadIdx.x;
+    const int split = blockIdx.x, b = blockIdx.y;
+    const int per = (hw + nsplit - 1) / nsplit;
+    const int p0 = split * per;
+    const int p1 = min(hw, p0 + per);
+    const int nq = C >> 2;
+    const int qw = nq < 256 ? nq : 256;     // quads handled side by side
+    const int rows = 256 / qw;              // pixel rows handled side by side
+    const int qi = tid % qw, r = tid / qw;
+    const bool active = r < rows;
+    const float* __restrict__ base = src + (size_t)b * hw * C;
+    for (int qb = 0; qb < nq; qb += qw) {
+        const int q = qb + qi;
+        double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+        if (active && q < nq) {
+            for (int p = p0 + r; p < p1; p += rows) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * C + q * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double d = (double)v[e];
+                    s[e] += d;
+                    ss[e] = fma(d, d, ss[e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[tid * 8 + e] = s[e];
+            red[tid * 8 + 4 + e] = ss[e];
+        }
+        __syncthreads();
+        if (r == 0 && q < nq) {
+            double* o = part + (((size_t)b * nsplit + split) * ctot + coff + q * 4) * 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double a = 0, c = 0;
+                for (int k = 0; k < rows; ++k) {   // fixed order
+                    a += red[(k * qw + qi) * 8 + e];
+                    c += red[(k * qw + qi) * 8 + 4 + e];
+                }
+                o[e * 2] = a;
+                o[e * 2 + 1] = c;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void gn_finalize(const double* __restrict__ part, int nsplit, int ctot, int groups,
+                                                  int hw, float eps, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float* __restrict__ scale,
+                                                  float* __restrict__ shift, float* __restrict__ mean_out,
+                                                  float* __restrict__ rstd_out) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int cpg = ctot / groups;
+    const int items = nsplit * cpg;
+    double s = 0, ss = 0;
+    for (int it = lane; it < items; it += 64) {
+        const int split = it / cpg, c = g * cpg + it % cpg;
+        const double* q = part + (((size_t)b * nsplit + split) * ctot + c) * 2;
+        s += q[0];
+        ss += q[1];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s += __shfl_xor(s, off);
+        ss += __shfl_xor(ss, off);
+    }
+    const double n = (double)hw * cpg;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    var = var < 0 ? 0 : var;
+    const float meanf = (float)mean;
+    const float rstdf = (float)(1.0 / sqrt(var + (double)eps));
+    if (lane == 0) {
+        if (mean_out) mean_out[b * groups + g] = meanf;
+        if (rstd_out) rstd_out[b * groups + g] = rstdf;
+    }
+    for (int k = lane; k < cpg; k += 64) {
+        const int c = g * cpg + k;
+        const float sc = rstdf * gamma[c];
+        scale[(size_t)b * ctot + c] = sc;
+        shift[(size_t)b * ctot + c] = -sc * meanf + beta[c];
+    }
+}
+
+}  // namespace
+
+extern "C" size_t cdx_gn_stats_f32_workspace(const cdx_gn_stats_args* a) {
+    if (!a || a->batch <= 0 || a->hw <= 0) return 0;
+    return (size_t)a->batch * gn_nsplit(a->hw) * (a->c0 + a->c1) * 2 * sizeof(double);
+}
+
+extern "C" int cdx_gn_stats_f32(const cdx_gn_stats_args* a, void* ws, size_t ws_bytes, cdx_stream_t stream) {
+    CDX_REQUIRE(a && a->src0 && a->gamma && a->beta && a->scale && a->shift);
+    CDX_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c0 % 4) == 0 && (a->c1 % 4) == 0);
+    CDX_REQUIRE((a->c1 == 0) == (a->src1 == nullptr));
+    CDX_REQUIRE(a->batch > 0 && a->batch <= 65535 && a->hw > 0 && a->groups > 0);
+    const int ctot = a->c0 + a->c1;
+    CDX_REQUIRE(ctot % a->groups == 0);
+    CDX_REQUIRE(aligned16(a->src0) && aligned16(a->src1) && aligned16(ws));
+    if (!ws || ws_bytes < cdx_gn_stats_f32_workspace(a)) return CDX_ENOSPC;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nsplit = gn_nsplit(a->hw);
+    double* part = static_cast<double*>(ws);
+    hipLaunchKernelGGL(gn_partial, dim3(nsplit, a->batch), dim3(256), 0, st, a->src0, a->c0, a->hw, nsplit, part, 0, ctot);
+    int rc = check_launch();
+    if (rc) return rc;
+    if (a->c1) {
+        hipLaunchKernelGGL(gn_partial, dim3(nsplit, a->batch), dim3(256), 0, st, a->src1, a->c1, a->hw, nsplit, part,
+                           a->c0, ctot);
+        if ((rc = check_launch())) return rc;
+    }
+    hipLaunchKernelGGL(gn_finalize, dim3(a->groups, a->batch), dim3(64), 0, st, part, nsplit, ctot, a->groups, a->hw,
+                       a->eps, a->gamma, a->beta, a->scale, a->shift, a->mean, a->rstd);
+    return check_launch();
+}

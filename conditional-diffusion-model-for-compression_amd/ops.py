@@ -1,0 +1,190 @@
+"""Functional wrappers: one call = one C-ABI op on torch CUDA tensors (NHWC float32).
+
+These mirror the torch.nn.functional calls they stand in for (F.conv2d / F.group_norm / F.linear /
+softmax-attention), with the fusions the kernels expose.  PyTorch is plumbing only here: it owns the
+device memory and the stream; all arithmetic happens in libcdx.so.  The UNet builds the same argument
+structs once and replays them (unet.py); these wrappers exist for tests and ad-hoc use.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _abi
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t, byte_off: int = 0):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32) and t.is_contiguous()
+    return t.data_ptr() + byte_off
+
+
+def _ws(nbytes: int, device):
+    if nbytes == 0:
+        return None, 0, None
+    buf = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.float64, device=device)
+    return buf.data_ptr(), nbytes, buf
+
+
+class PackedConv:
+    """Device-resident packed weights of one convolution (built once per layer)."""
+
+    def __init__(self, w_oihw, bias, c0: int, c1: int = 0, device="cuda"):
+        import numpy as np
+        w = np.asarray(w_oihw, dtype=np.float32)
+        self.cout, cin, self.ksize, _ = w.shape
+        assert cin == c0 + c1, (cin, c0, c1)
+        self.c0, self.c1 = c0, c1
+        self.w = torch.from_numpy(_abi.pack_conv_weights(w, c0, c1)).to(device)
+        self.bias = None if bias is None else torch.as_tensor(np.asarray(bias, np.float32)).to(device)
+
+
+def conv_args(pc: PackedConv, src0, src1, out, *, stride=1, upsample=False, gn=None, silu=False,
+              temb=None, temb_off=0, temb_ld=0, residual=None, out_ld=None) -> _abi.ConvArgs:
+    B, hin, win, c0 = src0.shape
+    assert c0 == pc.c0 and (src1 is None) == (pc.c1 == 0)
+    if src1 is not None:
+        assert tuple(src1.shape) == (B, hin, win, pc.c1)
+    hv, wv = (hin * 2, win * 2) if upsample else (hin, win)
+    hout, wout = (hv, wv) if stride == 1 else ((hv + 1) // 2, (wv + 1) // 2)
+    flags = (_abi.CONV_UPSAMPLE2X if upsample else 0) | (_abi.CONV_GN if gn is not None else 0) | \
+        (_abi.CONV_SILU if silu else 0)
+    a = _abi.ConvArgs()
+    a.src0, a.src1, a.c0, a.c1 = _ptr(src0), _ptr(src1), pc.c0, pc.c1
+    a.batch, a.hin, a.win, a.hout, a.wout = B, hin, win, hout, wout
+    a.cout, a.ksize, a.stride, a.flags = pc.cout, pc.ksize, stride, flags
+    a.wpacked, a.bias = _ptr(pc.w), _ptr(pc.bias)
+    if gn is not None:
+        a.gn_scale, a.gn_shift = _ptr(gn[0]), _ptr(gn[1])
+    if temb is not None:
+        a.temb, a.temb_ld = _ptr(temb, 4 * temb_off), temb_ld or temb.shape[-1]
+    a.residual = _ptr(residual)
+    a.out, a.out_ld = _ptr(out), out_ld or out.shape[-1]
+    assert out.shape[0] == B and out.shape[1] == hout and out.shape[2] == wout and a.out_ld >= pc.cout
+    return a
+
+
+def conv(pc: PackedConv, src0, src1=None, **kw):
+    """out = conv(silu(gn(cat[src0, src1]))) + bias (+ temb) (+ residual); NHWC in, NHWC out."""
+    B, hin, win, _ = src0.shape
+    up, stride = kw.get("upsample", False), kw.get("stride", 1)
+    hv, wv = (hin * 2, win * 2) if up else (hin, win)
+    hout, wout = (hv, wv) if stride == 1 else ((hv + 1) // 2, (wv + 1) // 2)
+    out = kw.pop("out", None)
+    if out is None:
+        out = torch.empty(B, hout, wout, kw.get("out_ld") or pc.cout, device=src0.device, dtype=torch.float32)
+        if out.shape[-1] != pc.cout:
+            out.zero_()
+    a = conv_args(pc, src0, src1, out, **kw)
+    _abi.call("conv_f32", a, None, 0, _stream())
+    return out
+
+
+def gn_stats_args(src0, src1, gamma, beta, groups, scale, shift, eps=1e-5, mean=None, rstd=None) -> _abi.GnStatsArgs:
+    B = src0.shape[0]
+    c0 = src0.shape[-1]
+    hw = src0.numel() // (B * c0)
+    a = _abi.GnStatsArgs()
+    a.src0, a.src1, a.c0, a.c1 = _ptr(src0), _ptr(src1), c0, (0 if src1 is None else src1.shape[-1])
+    a.batch, a.hw, a.groups, a.eps = B, hw, groups, eps
+    a.gamma, a.beta, a.scale, a.shift = _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift)
+    a.mean, a.rstd = _ptr(mean), _ptr(rstd)
+    return a
+
+
+def gn_stats(src0, src1, gamma, beta, groups, eps=1e-5, want_moments=False):
+    """(scale[B,C], shift[B,C]) such that group_norm(x)[b,...,c] = x*scale[b,c] + shift[b,c]."""
+    B = src0.shape[0]
+    C = src0.shape[-1] + (0 if src1 is None else src1.shape[-1])
+    dev = src0.device
+    scale = torch.empty(B, C, device=dev)
+    shift = torch.empty(B, C, device=dev)
+    mean = torch.empty(B, groups, device=dev) if want_moments else None
+    rstd = torch.empty(B, groups, device=dev) if want_moments else None
+    a = gn_stats_args(src0, src1, gamma, beta, groups, scale, shift, eps, mean, rstd)
+    wp, wb, keep = _ws(_abi.workspace_bytes("gn_stats_f32", a), dev)
+    _abi.call("gn_stats_f32", a, wp, wb, _stream())
+    return (scale, shift, mean, rstd) if want_moments else (scale, shift)
+
+
+def attn_args(q, k, v, out, *, batch, nq, nk, heads, head_dim, q_ld, k_ld, v_ld, out_ld,
+              q_off=0, k_off=0, v_off=0, scale=None) -> _abi.AttnArgs:
+    a = _abi.AttnArgs()
+    a.q, a.q_ld = _ptr(q, 4 * q_off), q_ld
+    a.k, a.k_ld = _ptr(k, 4 * k_off), k_ld
+    a.v, a.v_ld = _ptr(v, 4 * v_off), v_ld
+    a.batch, a.nq, a.nk, a.heads, a.head_dim = batch, nq, nk, heads, head_dim
+    a.scale = scale if scale is not None else head_dim ** -0.5
+    a.out, a.out_ld = _ptr(out), out_ld
+    return a
+
+
+def attention(q, k, v, heads: int, head_dim: int = 64):
+    """q [B,Nq,C], k/v [B,Nk,C] (C = heads*head_dim) -> softmax(q k^T / sqrt(d)) v  [B,Nq,C]."""
+    B, nq, c = q.shape
+    nk = k.shape[1]
+    out = torch.empty(B, nq, c, device=q.device)
+    a = attn_args(q, k, v, out, batch=B, nq=nq, nk=nk, heads=heads, head_dim=head_dim,
+                  q_ld=c, k_ld=k.shape[-1], v_ld=v.shape[-1], out_ld=c)
+    _abi.call("attn_f32", a, None, 0, _stream())
+    return out
+
+
+def linear_args(x, w, bias, out, *, silu_in=False, m=None, out_off=0, out_ld=None) -> _abi.LinearArgs:
+    a = _abi.LinearArgs()
+    a.x, a.x_ld = _ptr(x), x.shape[-1]
+    a.w, a.bias = _ptr(w), _ptr(bias)
+    a.m, a.n, a.k = (m or x.shape[0]), w.shape[0], w.shape[1]
+    a.flags = _abi.LINEAR_SILU_IN if silu_in else 0
+    a.out, a.out_ld = _ptr(out, 4 * out_off), out_ld or out.shape[-1]
+    return a
+
+
+def linear(x, w, bias=None, silu_in=False):
+    out = torch.empty(x.shape[0], w.shape[0], device=x.device)
+    _abi.call("linear_f32", linear_args(x, w, bias, out, silu_in=silu_in), None, 0, _stream())
+    return out
+
+
+def timestep_embedding(t, dim: int):
+    out = torch.empty(t.shape[0], dim, device=t.device)
+    a = _abi.TimestepEmbeddingArgs(_ptr(t), t.shape[0], dim, _ptr(out))
+    _abi.call("timestep_embedding_f32", a, None, 0, _stream())
+    return out
+
+
+def gauss_fill(x, channels: int, seed: int, first_image: int, noise_stream: int):
+    """x [B, HW.., ld] NHWC buffer: channels [0, channels) <- N(0,1) of stream (seed, image, noise_stream)."""
+    B, ld = x.shape[0], x.shape[-1]
+    a = _abi.GaussFillArgs(_ptr(x), ld, B, x.numel() // (B * ld), channels, seed, first_image, noise_stream)
+    _abi.call("gauss_fill_f32", a, None, 0, _stream())
+    return x
+
+
+def diffusion_update(x, eps, channels, coef, *, clip_x0=True, seed=0, first_image=0, noise_stream=0):
+    B, ld = x.shape[0], x.shape[-1]
+    a = _abi.DiffusionUpdateArgs(_ptr(x), ld, _ptr(eps), eps.shape[-1], B, x.numel() // (B * ld), channels,
+                                 coef.ca, coef.cb, coef.cx, coef.c0, coef.ce, coef.sigma, int(clip_x0),
+                                 seed, first_image, noise_stream)
+    _abi.call("diffusion_update_f32", a, None, 0, _stream())
+    return x
+
+
+def cond_embed(cond_nchw, x, c_off: int):
+    B, cc, hc, wc = cond_nchw.shape
+    _, h, w, ld = x.shape
+    a = _abi.CondEmbedArgs(_ptr(cond_nchw), cc, hc, wc, _ptr(x), ld, c_off, B, h, w)
+    _abi.call("cond_embed_f32", a, None, 0, _stream())
+    return x
+
+
+def export_image(x, channels: int, lo=-1.0, hi=1.0):
+    B, h, w, ld = x.shape
+    out = torch.empty(B, channels, h, w, device=x.device)
+    a = _abi.ExportImageArgs(_ptr(x), ld, B, h * w, channels, lo, hi, _ptr(out))
+    _abi.call("export_image_f32", a, None, 0, _stream())
+    return out

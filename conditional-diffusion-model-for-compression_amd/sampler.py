@@ -1,0 +1,66 @@
+"""Sampler(unet, schedule, method).sample(cond, steps) -- the reverse-diffusion loop (S2 of SURVEY.md 8a).
+
+The entry point BASELINE.json north_star names.  Per call: x_T is drawn on the device from the counter
+generator (stream keyed by the GLOBAL image index, so results do not depend on how a batch is sharded
+over GPUs), then `steps` iterations of {UNet forward (recorded launch list), one fused update kernel}.
+The loop body issues only C-ABI launches on the current stream: no allocation, no host sync, no
+device-to-host copy until the result is exported.
+
+The reference snapshot has no sampler to cite (README.md: 0 bytes); equations: schedule.py.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _abi, ops
+from .rng import STREAM_STEP0, STREAM_XT
+from .schedule import make_schedule, step_coefficients
+from .unet import UNet, load_cond
+
+
+class Sampler:
+    def __init__(self, unet: UNet, schedule: dict | None = None, method: str = "ddim", *,
+                 eta: float = 0.0, clip_x0: bool = True):
+        if method not in ("ddim", "ddpm"):
+            raise ValueError(f"method must be 'ddim' or 'ddpm', got {method!r}")
+        if eta != 0.0:
+            raise ValueError("only eta = 0 (deterministic DDIM) is defined")
+        self.unet, self.method, self.clip_x0 = unet, method, clip_x0
+        self.schedule = make_schedule(schedule)
+
+    @torch.no_grad()
+    def sample(self, cond: torch.Tensor, steps: int, *, seed: int = 0, first_image: int = 0,
+               trace: list | None = None) -> torch.Tensor:
+        """cond [B,Cc,hc,wc] or [B,L,D] -> x_0 [B,C,H,W] in [-1,1] on the UNet's device.
+
+        `first_image` is the global index of cond[0] (noise streams are keyed by global index).
+        """
+        net, cfg = self.unet, self.unet.cfg
+        B, C = cond.shape[0], cfg["in_channels"]
+        p = net.plan(B)
+        coefs = step_coefficients(self.schedule, steps, self.method)
+        st = torch.cuda.current_stream().cuda_stream
+        load_cond(p, cfg, cond)
+        ops.gauss_fill(p.xin, C, seed, first_image, STREAM_XT)
+        upd = _abi.DiffusionUpdateArgs()
+        upd.x, upd.x_ld, upd.eps, upd.eps_ld = p.xin.data_ptr(), p.xin.shape[-1], p.eps.data_ptr(), p.eps.shape[-1]
+        upd.batch, upd.hw, upd.channels = B, p.xin.shape[1] * p.xin.shape[2], C
+        upd.clip_x0, upd.seed, upd.first_image = int(self.clip_x0), seed, first_image
+        t_host = -1
+        for k, c in enumerate(coefs):
+            if c.t != t_host:
+                p.t.fill_(c.t)
+                t_host = c.t
+            p.run(st)
+            upd.ca, upd.cb, upd.cx, upd.c0, upd.ce, upd.sigma = c.ca, c.cb, c.cx, c.c0, c.ce, c.sigma
+            upd.noise_stream = STREAM_STEP0 + k
+            _abi.call("diffusion_update_f32", upd, None, 0, st)
+            if trace is not None:
+                trace.append(p.xin[..., :C].permute(0, 3, 1, 2).clone())
+        return ops.export_image(p.xin, C, -1.0, 1.0)
+
+
+def sample(unet: UNet, cond: torch.Tensor, steps: int, *, method: str = "ddim", schedule: dict | None = None,
+           seed: int = 0, **kw) -> torch.Tensor:
+    """Functional form of Sampler(unet, schedule, method).sample(cond, steps, seed=seed)."""
+    return Sampler(unet, schedule, method).sample(cond, steps, seed=seed, **kw)

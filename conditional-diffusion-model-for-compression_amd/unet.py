@@ -1,0 +1,253 @@
+"""UNet(cfg).forward(x, t, cond) -- the eps-prediction network (U0 of SURVEY.md section 8a) on the HIP path.
+
+Host side only: the constructor packs and uploads the weights; `plan(batch)` allocates every activation
+buffer ONCE (NHWC, resident in HBM for the whole sampling loop -- 288 GB makes reuse games pointless)
+and records the forward pass as a flat list of (C-ABI entry point, argument struct) pairs; `run()`
+replays that list on the current HIP stream with no Python-side tensor work, allocation or sync.
+Every arithmetic operation is a libcdx.so kernel; importing this module without the built library
+raises (no CPU fallback).
+
+API contract: BASELINE.json north_star ("same UNet config dict, same sample(cond, steps) entry point");
+the reference snapshot defines neither (README.md: 0 bytes), SURVEY.md Appendix A does.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _abi, ops
+from .config import validate_unet_config
+from .graph import build_graph
+from .params import init_params
+
+
+def _pad4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+class _Plan:
+    """All buffers + the recorded launch list for one batch size."""
+
+    def __init__(self, net: "UNet", batch: int):
+        self.net, self.batch = net, batch
+        cfg, g, dev = net.cfg, net.graph, net.device
+        B, H, ch = batch, cfg["image_size"], cfg["base_channels"]
+        self.calls = []          # (bound C function, args struct, ws_ptr, ws_bytes)
+        self._keep = []
+        self._ws_need = 0
+        self._ws_calls = []      # indices of calls that use the shared workspace
+        new = lambda *shape: self._hold(torch.empty(*shape, device=dev, dtype=torch.float32))  # noqa: E731
+
+        self.xin_ld = _pad4(g.cin_total)
+        self.xin = self._hold(torch.zeros(B, H, H, self.xin_ld, device=dev))     # x_t | cond | 0
+        self.eps = self._hold(torch.zeros(B, H, H, _pad4(cfg["out_channels"]), device=dev))
+        self.t = self._hold(torch.zeros(B, dtype=torch.int32, device=dev))
+        cross = cfg["cond_mode"] == "cross_attn"
+        self.ctx = None
+
+        # ---- timestep embedding MLP + every ResBlock's temb projection in one linear ----
+        emb0, emb1, emb2 = new(B, ch), new(B, g.temb_dim), new(B, g.temb_dim)
+        self.tproj = new(B, net.tproj_w.shape[0])
+        self._add("timestep_embedding_f32", _abi.TimestepEmbeddingArgs(self.t.data_ptr(), B, ch, emb0.data_ptr()))
+        self._add("linear_f32", ops.linear_args(emb0, net.dev["temb.0.weight"], net.dev["temb.0.bias"], emb1))
+        self._add("linear_f32", ops.linear_args(emb1, net.dev["temb.2.weight"], net.dev["temb.2.bias"], emb2, silu_in=True))
+        self._add("linear_f32", ops.linear_args(emb2, net.tproj_w, net.tproj_b, self.tproj, silu_in=True))
+
+        def gn(name, src0, src1=None):
+            c = src0.shape[-1] + (0 if src1 is None else src1.shape[-1])
+            sc, sh = new(B, c), new(B, c)
+            a = ops.gn_stats_args(src0, src1, net.dev[name + ".weight"], net.dev[name + ".bias"], cfg["groups"], sc, sh)
+            self._add("gn_stats_f32", a, ws=True)
+            return sc, sh
+
+        def conv(name, src0, src1=None, **kw):
+            pc = net.convs[name]
+            Bn, hin, win, _ = src0.shape
+            hv, wv = (2 * hin, 2 * win) if kw.get("upsample") else (hin, win)
+            s = kw.get("stride", 1)
+            out = kw.pop("out", None)
+            if out is None:
+                out = new(Bn, (hv + s - 1) // s, (wv + s - 1) // s, pc.cout)
+            self._add("conv_f32", ops.conv_args(pc, src0, src1, out, **kw))
+            return out
+
+        def res(blk, x, skip=None):
+            n = blk.name
+            h1 = conv(n + ".conv1", x, skip, gn=gn(n + ".norm1", x, skip), silu=True,
+                      temb=self.tproj, temb_off=net.tproj_off[n], temb_ld=self.tproj.shape[-1])
+            if blk.cin != blk.cout:
+                r = conv(n + ".skip", x, skip)
+            else:
+                assert skip is None
+                r = x
+            return conv(n + ".conv2", h1, gn=gn(n + ".norm2", h1), silu=True, residual=r)
+
+        def attn(blk, x):
+            n = blk.name
+            Bn, hh, ww, c = x.shape
+            qkv = conv(n + ".qkv", x, gn=gn(n + ".norm", x))
+            o = new(Bn, hh, ww, c)
+            self._add("attn_f32", ops.attn_args(qkv, qkv, qkv, o, batch=Bn, nq=hh * ww, nk=hh * ww,
+                                                 heads=c // cfg["head_dim"], head_dim=cfg["head_dim"],
+                                                 q_ld=3 * c, k_ld=3 * c, v_ld=3 * c, out_ld=c, k_off=c, v_off=2 * c))
+            return conv(n + ".proj", o, residual=x)
+
+        def xattn(blk, x):
+            n = blk.name
+            Bn, hh, ww, c = x.shape
+            q = conv(n + ".q", x, gn=gn(n + ".norm", x))
+            kv = conv(n + ".kv", self.ctx)                       # [B, lh, lw, 2c]
+            L = self.ctx.shape[1] * self.ctx.shape[2]
+            o = new(Bn, hh, ww, c)
+            self._add("attn_f32", ops.attn_args(q, kv, kv, o, batch=Bn, nq=hh * ww, nk=L,
+                                                 heads=c // cfg["head_dim"], head_dim=cfg["head_dim"],
+                                                 q_ld=c, k_ld=2 * c, v_ld=2 * c, out_ld=c, v_off=c))
+            return conv(n + ".proj", o, residual=x)
+
+        def run_block(blk, h, skip=None):
+            if blk.kind == "res":
+                return res(blk, h, skip)
+            if blk.kind == "attn":
+                return attn(blk, h)
+            if blk.kind == "xattn":
+                return xattn(blk, h)
+            if blk.kind == "down":
+                return conv(blk.name, h, stride=2)
+            if blk.kind == "up":
+                return conv(blk.name, h, upsample=True)
+            raise ValueError(blk.kind)
+
+        if cross:
+            L, D = (H // 16) ** 2, cfg["context_dim"]
+            lw = 32 if L % 32 == 0 else L
+            self.ctx = self._hold(torch.zeros(B, L // lw, lw, D, device=dev))
+
+        h = conv("conv_in", self.xin)
+        skips = [h]
+        for blk in g.down:
+            h = run_block(blk, h)
+            if blk.push_skip:
+                skips.append(h)
+        for blk in g.mid:
+            h = run_block(blk, h)
+        for blk in g.up:
+            h = run_block(blk, h, skips.pop() if blk.kind == "res" else None)
+        assert not skips
+        conv("out.conv", h, gn=gn("out.norm", h), silu=True, out=self.eps, out_ld=self.eps.shape[-1])
+
+        # one shared workspace (calls are serialised on one stream)
+        if self._ws_need:
+            self.ws = self._hold(torch.empty((self._ws_need + 7) // 8, dtype=torch.float64, device=dev))
+            for i in self._ws_calls:
+                fn, a, _, nbytes = self.calls[i]
+                self.calls[i] = (fn, a, self.ws.data_ptr(), nbytes)
+        self.activation_bytes = sum(t.numel() * t.element_size() for t in self._keep)
+
+    def _hold(self, t):
+        self._keep.append(t)
+        return t
+
+    def _add(self, op, args, ws=False):
+        nbytes = _abi.workspace_bytes(op, args) if ws else 0
+        if nbytes:
+            self._ws_need = max(self._ws_need, nbytes)
+            self._ws_calls.append(len(self.calls))
+        self.calls.append((getattr(_abi.lib(), f"cdx_{op}"), args, None, nbytes))
+
+    def run(self, stream: int | None = None):
+        """Enqueue one UNet forward: reads self.xin / self.t (/ self.ctx), writes self.eps."""
+        import ctypes
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        byref = ctypes.byref
+        for fn, a, wp, wb in self.calls:
+            rc = fn(byref(a), wp, wb, st)
+            if rc:
+                _abi.check(rc, fn.__name__)
+
+
+class UNet:
+    """unet = UNet(cfg_dict[, params]); eps = unet.forward(x, t, cond)."""
+
+    def __init__(self, cfg: dict, params: dict | None = None, *, seed: int = 0, device="cuda"):
+        _abi.lib()   # fail loudly now if the extension is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("UNet (HIP backend) needs a GPU; there is no CPU fallback in the product path")
+        self.cfg = validate_unet_config(cfg)
+        self.graph = build_graph(self.cfg)
+        self.device = torch.device(device)
+        if params is None:
+            params = init_params(self.cfg, seed)
+        g = self.graph
+        missing = set(g.param_shapes) - set(params)
+        if missing:
+            raise KeyError(f"params lack {sorted(missing)[:5]}...")
+        P = {k: np.asarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, np.float32)
+             for k, v in params.items()}
+        for k, shp in g.param_shapes.items():
+            if tuple(P[k].shape) != tuple(shp):
+                raise ValueError(f"param {k}: shape {P[k].shape} != {shp}")
+
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)  # noqa: E731
+        self.dev = {}      # small tensors used as-is: norms, linears
+        self.convs = {}    # name -> PackedConv
+        res_blocks = [b for b in g.down + g.mid + g.up if b.kind == "res"]
+        for name in g.param_shapes:
+            if name.endswith(".weight") and P[name].ndim == 4:
+                base = name[:-7]
+                w, bias = P[name], P[base + ".bias"]
+                c0, c1 = w.shape[1], 0
+                if base == "conv_in":
+                    cpad = _pad4(w.shape[1])
+                    w = np.pad(w, ((0, 0), (0, cpad - w.shape[1]), (0, 0), (0, 0)))
+                    c0 = cpad
+                for b in res_blocks:    # up-path ResBlocks read (x, skip) as two sources
+                    if b.skip_ch and base in (b.name + ".conv1", b.name + ".skip"):
+                        c0, c1 = b.cin - b.skip_ch, b.skip_ch
+                self.convs[base] = ops.PackedConv(w, bias, c0, c1, self.device)
+            elif ".norm" in name or name.startswith("temb."):
+                self.dev[name] = up(P[name])
+        for b in g.down + g.mid + g.up:
+            if b.kind == "xattn":   # kv projection of the context tokens runs as a 1x1 convolution
+                w = P[b.name + ".kv.weight"]
+                self.convs[b.name + ".kv"] = ops.PackedConv(w[:, :, None, None], P[b.name + ".kv.bias"],
+                                                            w.shape[1], 0, self.device)
+        # all ResBlock temb projections as one [sum(cout), temb_dim] linear
+        self.tproj_off, off = {}, 0
+        for b in res_blocks:
+            self.tproj_off[b.name] = off
+            off += b.cout
+        self.tproj_w = up(np.concatenate([P[b.name + ".temb.weight"] for b in res_blocks], 0))
+        self.tproj_b = up(np.concatenate([P[b.name + ".temb.bias"] for b in res_blocks], 0))
+        self.weight_bytes = sum(pc.w.numel() * 4 for pc in self.convs.values()) + self.tproj_w.numel() * 4
+        self._plans = {}
+
+    def plan(self, batch: int) -> _Plan:
+        if batch not in self._plans:
+            self._plans[batch] = _Plan(self, batch)
+        return self._plans[batch]
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, t: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
+        """x [B,C,H,W], t [B] int, cond [B,Cc,hc,wc] (concat) or [B,L,D] (cross_attn) -> eps [B,C,H,W]."""
+        cfg = self.cfg
+        B = x.shape[0]
+        p = self.plan(B)
+        dev = self.device
+        C = cfg["in_channels"]
+        p.xin[..., :C] = x.to(dev, torch.float32).permute(0, 2, 3, 1)
+        p.t.copy_(t.to(dev, torch.int32))
+        load_cond(p, cfg, cond)
+        p.run()
+        return p.eps[..., :cfg["out_channels"]].permute(0, 3, 1, 2).contiguous()
+
+    __call__ = forward
+
+
+def load_cond(p: _Plan, cfg: dict, cond: torch.Tensor) -> None:
+    dev = p.net.device
+    if cfg["cond_mode"] == "concat":
+        c = cond.to(dev, torch.float32).contiguous()
+        assert c.shape[1] == cfg["cond_channels"], c.shape
+        ops.cond_embed(c, p.xin, cfg["in_channels"])
+    else:
+        p.ctx.view(p.batch, -1, cfg["context_dim"]).copy_(cond.to(dev, torch.float32))

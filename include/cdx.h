@@ -1,0 +1,217 @@
+/*
+ * cdx.h -- C ABI of libcdx.so: the MI355X (gfx950) kernels behind the reverse-diffusion
+ * decode hot path (UNet forward + DDIM/DDPM update).
+ *
+ * Reference interface replaced: NONE EXISTS.  The reference snapshot (/root/reference) holds
+ * only an empty README.md (0 bytes) and a 27-line .gitignore (.gitignore:1-27); it has no
+ * operator / plugin / FFI interface for this path.  The boundary is the one BASELINE.json
+ * north_star dictates ("Python model/sampler API ... calling hand-written HIP kernels through a
+ * thin C-ABI extension") and SURVEY.md section 8(b) specifies.  Each entry point below names
+ * the SURVEY.md section 8(a) row (S-rows / U-rows) it implements; a reference-side torch.nn.functional
+ * call it stands in for is given where one is obvious.
+ *
+ * Conventions
+ *   - Every op:  int cdx_<op>(const cdx_<op>_args*, void* workspace, size_t workspace_bytes,
+ *                              cdx_stream_t stream);   size_t cdx_<op>_workspace(const args*);
+ *   - Returns CDX_OK or a negative status; never throws, aborts, allocates, frees or syncs
+ *     (safe under hipGraph capture).  All work is enqueued on `stream` (a hipStream_t).
+ *   - All pointers are DEVICE pointers owned by the caller, 16-byte aligned.
+ *   - Activations are dense NHWC float32: x[b][y][x][c]; channel counts are multiples of 4.
+ *   - Stateless and re-entrant: no global mutable state.
+ */
+#ifndef CDX_H
+#define CDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDX_ABI_VERSION 1
+
+typedef void* cdx_stream_t; /* hipStream_t */
+
+enum {
+    CDX_OK = 0,
+    CDX_EINVAL = -1,  /* bad shape / null / misaligned pointer */
+    CDX_ENOSPC = -2,  /* workspace too small */
+    CDX_ELAUNCH = -3, /* hipGetLastError() != hipSuccess after the launch */
+    CDX_ENOTSUP = -4  /* valid request this build has no kernel for */
+};
+
+int cdx_abi_version(void);
+const char* cdx_strerror(int status);
+
+/* ------------------------------------------------------------------------------------------
+ * U3/U4/U5/U8/U9: convolution as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Stands in for F.conv2d(silu(group_norm(cat[src0, src1]))) + bias + temb[:, :, None, None]
+ * + residual, with nearest-2x upsampling and channel concat fused into the tile gather.
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    CDX_CONV_UPSAMPLE2X = 1, /* sources are nearest-upsampled x2 before the conv (U5) */
+    CDX_CONV_GN = 2,         /* apply x*gn_scale[b][c] + gn_shift[b][c] while staging (U2) */
+    CDX_CONV_SILU = 4        /* then x * sigmoid(x) (U2) */
+};
+
+#define CDX_CONV_KC 32 /* input-channel chunk of the packed weight layout */
+
+typedef struct cdx_conv_args {
+    const float* src0;     /* [batch, hin, win, c0] */
+    const float* src1;     /* [batch, hin, win, c1] or NULL: channel-concatenated after src0 */
+    int32_t c0, c1;        /* multiples of 4; with two sources both multiples of CDX_CONV_KC */
+    int32_t batch, hin, win;
+    int32_t hout, wout;    /* stride 1: = (2x) hin,win; stride 2: = ceil(hin/2), ceil(win/2) */
+    int32_t cout;
+    int32_t ksize;         /* 1 or 3 (pad = ksize/2) */
+    int32_t stride;        /* 1 or 2 */
+    int32_t flags;         /* CDX_CONV_* */
+    const float* wpacked;  /* cdx_conv_pack_weights_f32 output, uploaded */
+    const float* bias;     /* [cout] or NULL */
+    const float* gn_scale; /* [batch, c0+c1] (CDX_CONV_GN) from cdx_gn_stats_f32 */
+    const float* gn_shift; /* [batch, c0+c1] */
+    const float* temb;     /* [batch, temb_ld] or NULL: out += temb[b*temb_ld + co] */
+    int32_t temb_ld;
+    const float* residual; /* [batch, hout, wout, cout] or NULL: out += residual */
+    float* out;            /* [batch, hout, wout, out_ld], channels [0, cout) written */
+    int32_t out_ld;
+} cdx_conv_args;
+
+int cdx_conv_f32(const cdx_conv_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_conv_f32_workspace(const cdx_conv_args* a);
+
+/* HOST helper: number of floats of the packed weight image, and the packer.
+ * w_oihw: host [cout][c0+c1][ksize][ksize] (torch layout).  Packed layout:
+ *   [ntile = ceil(cout/32)][chunk][tap = ky*ksize+kx][s = 0..3][lane = 0..63][e = 0..3]
+ *   = W[n = 32*ntile + (lane&31)][c = chunk_base + 8*s + 4*(lane>>5) + e][ky][kx]
+ * chunks: ceil(c0/32) of src0 then ceil(c1/32) of src1, zero-filled past each source's end. */
+size_t cdx_conv_packed_floats(int32_t c0, int32_t c1, int32_t cout, int32_t ksize);
+int cdx_conv_pack_weights_f32(const float* w_oihw, int32_t c0, int32_t c1, int32_t cout,
+                              int32_t ksize, float* packed);
+
+/* ------------------------------------------------------------------------------------------
+ * U2: GroupNorm statistics of cat[src0, src1] -> per-(batch, channel) scale / shift
+ *   scale[b][c] = rstd[b][g(c)] * gamma[c];  shift[b][c] = beta[c] - mean[b][g(c)] * scale[b][c]
+ * (F.group_norm's own two-step form).  Sums are carried in float64, fixed order (deterministic).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cdx_gn_stats_args {
+    const float* src0;  /* [batch, hw, c0] */
+    const float* src1;  /* [batch, hw, c1] or NULL */
+    int32_t c0, c1;
+    int32_t batch, hw;
+    int32_t groups;
+    float eps;
+    const float* gamma; /* [c0+c1] */
+    const float* beta;  /* [c0+c1] */
+    float* scale;       /* [batch, c0+c1] */
+    float* shift;       /* [batch, c0+c1] */
+    float* mean;        /* [batch, groups] or NULL (diagnostic) */
+    float* rstd;        /* [batch, groups] or NULL */
+} cdx_gn_stats_args;
+
+int cdx_gn_stats_f32(const cdx_gn_stats_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_gn_stats_f32_workspace(const cdx_gn_stats_args* a);
+
+/* ------------------------------------------------------------------------------------------
+ * U6/U7: multi-head attention core  out = softmax(q k^T * scale) v  on fp32 MFMA.
+ * Token-major operands: q[b][i][h*head_dim + d] with leading dimension q_ld, etc.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cdx_attn_args {
+    const float* q; int32_t q_ld;
+    const float* k; int32_t k_ld;
+    const float* v; int32_t v_ld;
+    int32_t batch, nq, nk, heads, head_dim; /* head_dim == 64 */
+    float scale;
+    float* out; int32_t out_ld;             /* [batch, nq, out_ld] */
+} cdx_attn_args;
+
+int cdx_attn_f32(const cdx_attn_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_attn_f32_workspace(const cdx_attn_args* a);
+
+/* ------------------------------------------------------------------------------------------
+ * U1: small-M linear  out[m][n] = sum_k act(x[m][k]) * w[n][k] + bias[n]   (F.linear)
+ * ------------------------------------------------------------------------------------------ */
+enum { CDX_LINEAR_SILU_IN = 1 };
+
+typedef struct cdx_linear_args {
+    const float* x; int32_t x_ld; /* [m, x_ld] */
+    const float* w;               /* [n, k] row-major (torch layout) */
+    const float* bias;            /* [n] or NULL */
+    int32_t m, n, k;              /* k multiple of 4, m <= 64 */
+    int32_t flags;
+    float* out; int32_t out_ld;
+} cdx_linear_args;
+
+int cdx_linear_f32(const cdx_linear_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_linear_f32_workspace(const cdx_linear_args* a);
+
+/* U1: sinusoidal timestep embedding  out[b] = [sin(t_b f_k), cos(t_b f_k)], f_k = exp(-ln(1e4) k/(half-1)),
+ * evaluated in float64 and rounded to float32. */
+typedef struct cdx_timestep_embedding_args {
+    const int32_t* t; /* [batch] */
+    int32_t batch, dim;
+    float* out;       /* [batch, dim] */
+} cdx_timestep_embedding_args;
+
+int cdx_timestep_embedding_f32(const cdx_timestep_embedding_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_timestep_embedding_f32_workspace(const cdx_timestep_embedding_args* a);
+
+/* ------------------------------------------------------------------------------------------
+ * S3/S4: one reverse-diffusion update on channels [0, channels) of an NHWC buffer, in place:
+ *   x0h = clamp(ca*x + cb*eps, -1, 1) (clamp iff clip_x0);  x = cx*x + c0*x0h + ce*eps + sigma*z
+ * z = N(0,1) from the counter generator, stream (seed, first_image + b, noise_stream), element
+ * index (c*hw + pixel) (i.e. the NCHW flat index), only evaluated when sigma != 0.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cdx_diffusion_update_args {
+    float* x; int32_t x_ld;           /* [batch, hw, x_ld] */
+    const float* eps; int32_t eps_ld; /* [batch, hw, eps_ld] */
+    int32_t batch, hw, channels;
+    float ca, cb, cx, c0, ce, sigma;
+    int32_t clip_x0;
+    uint64_t seed; int64_t first_image; int32_t noise_stream;
+} cdx_diffusion_update_args;
+
+int cdx_diffusion_update_f32(const cdx_diffusion_update_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_diffusion_update_f32_workspace(const cdx_diffusion_update_args* a);
+
+/* S4: x[b][p][c] = N(0,1), c < channels, same generator / indexing as above (x_T uses stream 1). */
+typedef struct cdx_gauss_fill_args {
+    float* x; int32_t x_ld;
+    int32_t batch, hw, channels;
+    uint64_t seed; int64_t first_image; int32_t noise_stream;
+} cdx_gauss_fill_args;
+
+int cdx_gauss_fill_f32(const cdx_gauss_fill_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_gauss_fill_f32_workspace(const cdx_gauss_fill_args* a);
+
+/* U8: write nearest-resized cond (NCHW [batch, cc, hc, wc]) into channels [c_off, c_off+cc) of an NHWC
+ * buffer [batch, h, w, x_ld] and zero channels [c_off+cc, x_ld)  (F.interpolate(mode="nearest") + cat). */
+typedef struct cdx_cond_embed_args {
+    const float* cond; int32_t cc, hc, wc;
+    float* x; int32_t x_ld; int32_t c_off;
+    int32_t batch, h, w;
+} cdx_cond_embed_args;
+
+int cdx_cond_embed_f32(const cdx_cond_embed_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_cond_embed_f32_workspace(const cdx_cond_embed_args* a);
+
+/* S2 (exit): out NCHW [batch, channels, hw] = clamp(x[b][p][c], lo, hi). */
+typedef struct cdx_export_image_args {
+    const float* x; int32_t x_ld;
+    int32_t batch, hw, channels;
+    float lo, hi;
+    float* out;
+} cdx_export_image_args;
+
+int cdx_export_image_f32(const cdx_export_image_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_export_image_f32_workspace(const cdx_export_image_args* a);
+
+/* Diagnostics: monotonically counts kernel launches made through this library (relaxed atomic;
+ * the only process-global the library keeps, used by tests to prove the HIP path ran). */
+uint64_t cdx_launch_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDX_H */

@@ -1,0 +1,254 @@
+"""Per-kernel parity: every C-ABI op against the stock-torch CPU statement of the same op
+(float64 where cheap), on random and adversarial shapes.  Needs a GPU: run with -m gpu."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cdx_mod(lib):
+    import cdx
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return cdx
+
+
+def nhwc(t):   # NCHW cpu -> NHWC cuda
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):   # NHWC cuda -> NCHW cpu
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale).float()
+
+
+def close(got, want, tol, what=""):
+    want = want.to(torch.float64)
+    err = (got.to(torch.float64) - want).abs().max().item()
+    ref = max(want.abs().max().item(), 1e-30)
+    assert err <= tol * ref, f"{what}: max abs err {err:.3e} vs ref scale {ref:.3e} (tol {tol})"
+
+
+# ------------------------------------------------------------------ convolution
+CONV_CASES = [
+    # (B, Cin, Cout, H, W, ksize, stride, upsample)
+    (2, 32, 128, 32, 32, 3, 1, False),     # TW=32 main variant (1x4x4)
+    (1, 64, 160, 16, 16, 3, 1, False),     # TW=16, cout not a multiple of 128 (partial N block)
+    (2, 128, 64, 8, 8, 3, 1, False),       # TW=8, 2x2x2 wave layout
+    (3, 32, 32, 4, 4, 3, 1, False),        # TW=4, 4x1x1 layout, image smaller than a tile
+    (1, 8, 48, 40, 24, 3, 1, False),       # Cin < chunk (zero-filled), ragged H and W
+    (2, 32, 3, 32, 32, 3, 1, False),       # conv_out shape: cout = 3
+    (2, 64, 96, 32, 32, 1, 1, False),      # 1x1
+    (1, 32, 256, 12, 20, 1, 1, False),     # 1x1 ragged
+    (2, 32, 128, 32, 32, 3, 2, False),     # stride 2 (1x4x2)
+    (1, 64, 64, 18, 10, 3, 2, False),      # stride 2, odd-ish sizes, 2x2x1
+    (2, 32, 128, 16, 16, 3, 1, True),      # nearest-2x upsample fused
+    (1, 64, 64, 5, 7, 3, 1, True),         # upsample, ragged
+    (1, 96, 128, 64, 64, 3, 1, False),     # 3 chunks, multiple tiles in x and y
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_plain(cdx_mod, case):
+    B, ci, co, H, W, k, s, up = case
+    x = rnd(B, ci, H, W, seed=1)
+    w = rnd(co, ci, k, k, seed=2, scale=1.0 / math.sqrt(ci * k * k))
+    bias = rnd(co, seed=3)
+    xin = F.interpolate(x.double(), scale_factor=2, mode="nearest") if up else x.double()
+    want = F.conv2d(xin, w.double(), bias.double(), stride=s, padding=k // 2)
+    pc = cdx_mod.ops.PackedConv(w.numpy(), bias.numpy(), ci)
+    got = nchw(cdx_mod.ops.conv(pc, nhwc(x), stride=s, upsample=up))
+    assert got.shape == want.shape
+    close(got, want, 2e-6, "conv")
+
+
+@pytest.mark.parametrize("B,c0,c1,co,H,W,groups", [
+    (2, 64, 0, 128, 32, 32, 32),
+    (2, 64, 32, 64, 16, 16, 32),      # concat, group straddles the two sources (96/32 = 3 per group)
+    (1, 128, 64, 96, 8, 8, 32),       # concat, 6 channels / group
+    (2, 32, 0, 32, 4, 4, 8),
+])
+def test_conv_fused_gn_silu_concat_temb_residual(cdx_mod, B, c0, c1, co, H, W, groups):
+    """The whole first half of a ResBlock in one launch pair: conv3x3(silu(gn(cat[x, skip]))) + bias +
+    temb[:, :, None, None] + residual."""
+    ops = cdx_mod.ops
+    x0 = rnd(B, c0, H, W, seed=4) * 2.0 + 0.7          # non-zero mean
+    x1 = rnd(B, c1, H, W, seed=5) * 0.5 - 1.0 if c1 else None
+    ci = c0 + c1
+    gamma, beta = 1 + 0.2 * rnd(ci, seed=6), 0.3 * rnd(ci, seed=7)
+    w = rnd(co, ci, 3, 3, seed=8, scale=1.0 / math.sqrt(ci * 9))
+    bias, temb, res = rnd(co, seed=9), rnd(B, co + 5, seed=10), rnd(B, co, H, W, seed=11)
+    xc = torch.cat([x0, x1], 1) if c1 else x0
+    h = F.silu(F.group_norm(xc.double(), groups, gamma.double(), beta.double(), eps=1e-5))
+    want = F.conv2d(h, w.double(), bias.double(), padding=1) + temb[:, 2:2 + co].double()[:, :, None, None] + res.double()
+
+    s0, s1 = nhwc(x0), (nhwc(x1) if c1 else None)
+    sc, sh, mean, rstd = ops.gn_stats(s0, s1, gamma.cuda(), beta.cuda(), groups, want_moments=True)
+    # statistics themselves
+    xg = xc.double().reshape(B, groups, -1)
+    close(mean.cpu(), xg.mean(-1), 1e-6, "gn mean")
+    close(rstd.cpu(), (xg.var(-1, unbiased=False) + 1e-5).rsqrt(), 1e-6, "gn rstd")
+    pc = ops.PackedConv(w.numpy(), bias.numpy(), c0, c1)
+    got = nchw(ops.conv(pc, s0, s1, gn=(sc, sh), silu=True, temb=temb.cuda(), temb_off=2, residual=nhwc(res)))
+    close(got, want, 3e-6, "fused conv")
+
+
+def test_gn_no_silu_1x1(cdx_mod):
+    """Attention's qkv projection: conv1x1(gn(x)), no activation."""
+    ops = cdx_mod.ops
+    B, C, H, W = 2, 64, 8, 8
+    x = rnd(B, C, H, W, seed=12)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=13), 0.1 * rnd(C, seed=14)
+    w, bias = rnd(3 * C, C, 1, 1, seed=15, scale=1 / 8), rnd(3 * C, seed=16)
+    want = F.conv2d(F.group_norm(x.double(), 32, gamma.double(), beta.double()), w.double(), bias.double())
+    s0 = nhwc(x)
+    got = nchw(ops.conv(ops.PackedConv(w.numpy(), bias.numpy(), C), s0,
+                        gn=ops.gn_stats(s0, None, gamma.cuda(), beta.cuda(), 32)))
+    close(got, want, 3e-6, "gn+1x1")
+
+
+def test_gn_adversarial_moments(cdx_mod):
+    """Large mean / small variance, and a zero-variance group: float64 accumulation must hold."""
+    ops = cdx_mod.ops
+    B, C, H, W, G = 2, 64, 16, 16, 32
+    x = rnd(B, C, H, W, seed=17) * 1e-3 + 100.0
+    x[:, 0:2] = 5.0                                      # group 0: zero variance
+    gamma, beta = torch.ones(C), torch.zeros(C)
+    _, _, mean, rstd = ops.gn_stats(nhwc(x), None, gamma.cuda(), beta.cuda(), G, want_moments=True)
+    xg = x.double().reshape(B, G, -1)
+    close(mean.cpu(), xg.mean(-1), 1e-7, "mean")
+    want_rstd = (xg.var(-1, unbiased=False) + 1e-5).rsqrt()
+    assert torch.allclose(rstd.cpu().double(), want_rstd, rtol=2e-4), (rstd.cpu()[0, :4], want_rstd[0, :4])
+    assert torch.isfinite(rstd).all()
+
+
+def test_gn_stats_independent_of_batch(cdx_mod):
+    """Image i's statistics are bit-identical whether it is decoded alone or inside a batch (sharding invariance)."""
+    ops = cdx_mod.ops
+    x = nhwc(rnd(3, 64, 32, 32, seed=18))
+    g, b = torch.ones(64).cuda(), torch.zeros(64).cuda()
+    sc, sh = ops.gn_stats(x, None, g, b, 32)
+    sc1, sh1 = ops.gn_stats(x[1:2].contiguous(), None, g, b, 32)
+    assert torch.equal(sc[1:2], sc1) and torch.equal(sh[1:2], sh1)
+
+
+# ------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,heads,nq,nk", [(2, 2, 256, 256), (1, 4, 64, 64), (2, 1, 100, 77), (1, 2, 16, 1024), (1, 1, 300, 40)])
+def test_attention(cdx_mod, B, heads, nq, nk):
+    hd = 64
+    C = heads * hd
+    q, k, v = rnd(B, nq, C, seed=20), rnd(B, nk, C, seed=21), rnd(B, nk, C, seed=22)
+    qh = q.double().reshape(B, nq, heads, hd).transpose(1, 2)
+    kh = k.double().reshape(B, nk, heads, hd).transpose(1, 2)
+    vh = v.double().reshape(B, nk, heads, hd).transpose(1, 2)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(hd), -1)
+    want = (p @ vh).transpose(1, 2).reshape(B, nq, C)
+    got = cdx_mod.ops.attention(q.cuda(), k.cuda(), v.cuda(), heads).cpu()
+    close(got, want, 3e-6, "attention")
+
+
+def test_attention_peaked_rows(cdx_mod):
+    """One key dominates a row by a wide margin (exp underflow of the rest), another row is flat."""
+    B, heads, n, hd = 1, 1, 64, 64
+    q, k, v = rnd(B, n, hd, seed=23), rnd(B, n, hd, seed=24), rnd(B, n, hd, seed=25)
+    k[0, 7] = q[0, 3] * 40.0
+    q[0, 5] = 0.0
+    s = (q.double() @ k.double().transpose(-1, -2)) / 8.0
+    want = torch.softmax(s, -1) @ v.double()
+    got = cdx_mod.ops.attention(q.cuda(), k.cuda(), v.cuda(), heads).cpu()
+    close(got, want, 3e-6, "attention peaked")
+
+
+# ------------------------------------------------------------------ linear / temb
+@pytest.mark.parametrize("M,N,K,silu", [(16, 512, 128, False), (16, 512, 512, True), (1, 1000, 256, True), (3, 37, 64, False), (64, 64, 256, True)])
+def test_linear(cdx_mod, M, N, K, silu):
+    x, w, b = rnd(M, K, seed=30), rnd(N, K, seed=31, scale=1 / math.sqrt(K)), rnd(N, seed=32)
+    xin = F.silu(x.double()) if silu else x.double()
+    want = F.linear(xin, w.double(), b.double())
+    got = cdx_mod.ops.linear(x.cuda(), w.cuda(), b.cuda(), silu_in=silu).cpu()
+    close(got, want, 2e-6, "linear")
+
+
+def test_timestep_embedding(cdx_mod):
+    import oracle
+    t = torch.tensor([0, 1, 10, 500, 999], dtype=torch.int32)
+    for dim in (64, 128, 192):
+        want = oracle.timestep_embedding_ref(t.long(), dim)
+        got = cdx_mod.ops.timestep_embedding(t.cuda(), dim).cpu()
+        assert (got - want).abs().max().item() <= 1.2e-7, dim     # float64 evaluation, one rounding
+
+
+# ------------------------------------------------------------------ RNG / update / entry-exit copies
+def test_gauss_fill_matches_oracle_generator(cdx_mod):
+    import oracle
+    B, H, W, C, ld = 3, 16, 8, 3, 8
+    x = torch.full((B, H, W, ld), 7.0, device="cuda")
+    cdx_mod.ops.gauss_fill(x, C, seed=11, first_image=5, noise_stream=1)
+    got = x.cpu()
+    assert (got[..., C:] == 7.0).all()                              # other channels untouched
+    for b in range(B):
+        want = oracle.normal_ref(oracle.stream_key_ref(11, 5 + b, 1), C * H * W).reshape(C, H, W)
+        g = got[b, ..., :C].permute(2, 0, 1).numpy()
+        # float64 log / cos differ by <= 1 ulp(double) between libm and the device: after rounding to
+        # float32 the values agree bit for bit except (at most) at rare rounding ties.
+        assert np.abs(g - want).max() <= 2.4e-7 * max(1.0, np.abs(want).max())
+        assert (g == want).mean() > 0.999
+    # moments of a larger draw
+    y = torch.empty(1, 256, 256, 4, device="cuda")
+    cdx_mod.ops.gauss_fill(y, 3, seed=1, first_image=0, noise_stream=1)
+    z = y[..., :3].double()
+    assert abs(z.mean().item()) < 0.01 and abs(z.std().item() - 1.0) < 0.01
+
+
+@pytest.mark.parametrize("method", ["ddim", "ddpm"])
+def test_diffusion_update(cdx_mod, method):
+    import oracle
+    B, H, W, C = 2, 8, 8, 3
+    coefs = cdx_mod.step_coefficients(cdx_mod.make_schedule(), 50, method)
+    for k in (0, 17, 49):
+        c = coefs[k]
+        x, eps = rnd(B, C, H, W, seed=40 + k), rnd(B, C, H, W, seed=41 + k)
+        xb = torch.zeros(B, H, W, 8, device="cuda")
+        xb[..., :C] = nhwc(x)
+        xb[..., C:] = 3.0
+        eb = torch.zeros(B, H, W, 4, device="cuda")
+        eb[..., :C] = nhwc(eps)
+        cdx_mod.ops.diffusion_update(xb, eb, C, c, clip_x0=True, seed=9, first_image=4, noise_stream=16 + k)
+        x0 = (c.ca * x + c.cb * eps).clamp(-1, 1)
+        want = c.cx * x + c.c0 * x0 + c.ce * eps
+        if c.sigma != 0.0:
+            z = torch.from_numpy(np.stack([oracle.normal_ref(oracle.stream_key_ref(9, 4 + b, 16 + k), C * H * W).reshape(C, H, W) for b in range(B)]))
+            want = want + c.sigma * z
+        got = nchw(xb[..., :C].contiguous())
+        assert (got - want).abs().max().item() <= 5e-7
+        assert (xb[..., C:] == 3.0).all()
+
+
+def test_cond_embed_and_export(cdx_mod):
+    B, cc, hc, wc, H, W = 2, 3, 2, 4, 32, 32
+    cond = rnd(B, cc, hc, wc, seed=50)
+    x = torch.full((B, H, W, 8), 9.0, device="cuda")
+    cdx_mod.ops.cond_embed(cond.cuda(), x, 3)
+    want = F.interpolate(cond, size=(H, W), mode="nearest")
+    assert torch.equal(nchw(x[..., 3:6].contiguous()), want)
+    assert (x[..., 6:] == 0).all() and (x[..., :3] == 9.0).all()
+    x[..., :3] = nhwc(rnd(B, 3, H, W, seed=51) * 2)
+    out = cdx_mod.ops.export_image(x, 3).cpu()
+    assert torch.equal(out, nchw(x[..., :3].contiguous()).clamp(-1, 1))
+
+
+def test_bad_arguments_return_einval_not_crash(cdx_mod):
+    import ctypes
+    a = cdx_mod._abi.ConvArgs()                     # all-null
+    rc = cdx_mod._abi.lib().cdx_conv_f32(ctypes.byref(a), None, 0, None)
+    assert rc == -1
+    with pytest.raises(cdx_mod._abi.CdxError):
+        cdx_mod._abi.check(rc, "conv")
