@@ -5,6 +5,14 @@ deterministic, library-version-independent function of (cfg, seed): fan-in-scale
 uniform for conv / linear weights and biases (PyTorch-default-like bound 1/sqrt(fan_in)),
 GroupNorm gamma = 1, beta = 0 (optionally jittered for tests).  Arrays use torch layouts
 (conv OIHW, linear [out, in]) so the same dict feeds the oracle and the HIP backend.
+
+OUT_GAIN: the output convolution's weight is scaled by 0.05 (the canonical DDPM UNet zero-initialises
+it).  Measured reason: with gain 1 a RANDOM-weight eps-network makes the reverse chain chaotic -- the
+stock-torch oracle run with 8 threads vs 1 thread then agrees to only 18 dB after 50 DDIM steps
+(error x2 per step), so no PSNR gate could mean anything.  With gain 0.05 the same comparison gives
+112 dB on cfg1 and on a 5-level net (0.07: 103 dB, 0.1: 73 dB, 0.03: 121 dB), i.e. errors are carried
+roughly neutrally: the 80 dB / 0.01 dB gates are meaningful and still see per-step kernel error.
+Single-forward parity tests use out_gain = 1 (full sensitivity, no trajectory involved).
 """
 from __future__ import annotations
 
@@ -15,8 +23,10 @@ import numpy as np
 from . import rng
 from .graph import build_graph
 
+OUT_GAIN = 0.05
 
-def init_params(cfg: dict, seed: int = 0, affine_jitter: float = 0.0) -> dict:
+
+def init_params(cfg: dict, seed: int = 0, affine_jitter: float = 0.0, out_gain: float = OUT_GAIN) -> dict:
     g = build_graph(cfg)
     params = {}
     for pidx, (name, shape) in enumerate(g.param_shapes.items()):
@@ -36,6 +46,8 @@ def init_params(cfg: dict, seed: int = 0, affine_jitter: float = 0.0) -> dict:
                 fan_in = int(np.prod(g.param_shapes[name[:-5] + ".weight"][1:]))
             bound = 1.0 / math.sqrt(fan_in)
             v = (2.0 * rng.uniform(key, n) - 1.0) * bound
+            if name == "out.conv.weight":
+                v = v * out_gain
         params[name] = v.astype(np.float32).reshape(shape)
     return params
 

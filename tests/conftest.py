@@ -20,3 +20,16 @@ def lib():
         import __graft_entry__ as g
         g.build()
     return cdx._abi.lib()
+
+
+@pytest.fixture(scope="session")
+def record():
+    """record(name, **numbers): appends measured error levels to gpurun_out/metrics.jsonl (kept as evidence)."""
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+
+    def _rec(name, **kw):
+        with open(os.path.join(out, "metrics.jsonl"), "a") as f:
+            f.write(json.dumps({"test": name, **kw}) + "\n")
+    return _rec
