@@ -36,13 +36,12 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)" (spec
 
 
 def conv_variant(a) -> tuple:
-    """Mirror of the tile-shape selection in csrc/conv.hip: (ksize, stride, log2 TW, wave layout)."""
+    """(ksize, stride, log2 TW, tile shape) of the kernel instantiation libcdx picks for this launch."""
+    import ctypes
+    import cdx
     logtw = 5 if a.wout >= 32 else 4 if a.wout >= 16 else 3 if a.wout >= 8 else 2
-    if a.stride == 2:
-        w = "2x2x1" if a.cout <= 64 else "1x4x2"
-    else:
-        w = "4x1x1" if a.cout <= 32 else "2x2x2" if a.cout <= 64 else "1x4x4"
-    return (a.ksize, a.stride, logtw, w)
+    tile = cdx._abi.lib().cdx_conv_select_tile(ctypes.byref(a))
+    return (a.ksize, a.stride, logtw, cdx._abi.TILE_NAMES[tile])
 
 
 def conv_flops(a) -> float:
@@ -69,7 +68,7 @@ def measure_dominant_kernel(plan, torch, reps=3):
     import ctypes
     st = torch.cuda.current_stream()
     convs = [(i, c) for i, c in enumerate(plan.calls) if c[0].__name__ == "cdx_conv_f32"]
-    table = {}
+    table, shapes = {}, {}
     for rep in range(reps + 1):
         evs = []
         for i, (fn, a, wp, wb) in enumerate(plan.calls):
@@ -85,22 +84,29 @@ def measure_dominant_kernel(plan, torch, reps=3):
         if rep == 0:
             continue   # warm-up
         for a, e0, e1 in evs:
+            ms = e0.elapsed_time(e1)
             t = table.setdefault(conv_variant(a), {"flops": 0.0, "ms": 0.0, "launches": 0})
             t["flops"] += conv_flops(a)
-            t["ms"] += e0.elapsed_time(e1)
+            t["ms"] += ms
             t["launches"] += 1
+            sk = "k%ds%d %3dx%-3d %4d->%-4d %s" % (a.ksize, a.stride, a.hout, a.wout, a.c0 + a.c1, a.cout, conv_variant(a)[3])
+            u = shapes.setdefault(sk, {"flops": 0.0, "ms": 0.0, "n": 0})
+            u["flops"] += conv_flops(a); u["ms"] += ms; u["n"] += 1
     dom = max(table, key=lambda k: table[k]["flops"])
     d = table[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "kernel": "conv_kernel<ConvCfg<%d,%d,%d,%s>>" % dom,
+            "kernel": "conv_kernel<ConvCfg<ksize %d, stride %d, log2TW %d, tile %s>>" % dom,
             "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_forward": d["launches"] // reps,
             "flop_share_of_forward": round(d["flops"] / sum(v["flops"] for v in table.values()), 4)}
     per_variant = {"k%ds%d_tw%d_%s" % k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                          "ms_per_forward": round(v["ms"] / reps, 3)}
                    for k, v in sorted(table.items(), key=lambda kv: -kv[1]["flops"])}
-    return roof, per_variant
+    per_shape = {k: {"launches": v["n"] // reps, "ms_per_forward": round(v["ms"] / reps, 3),
+                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                 for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])}
+    return roof, {"variants": per_variant, "shapes": per_shape}
 
 
 def host_cores() -> int:

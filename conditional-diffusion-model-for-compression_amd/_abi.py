@@ -86,8 +86,10 @@ OPS = {
 }
 
 # every exported symbol include/cdx.h declares (checked by tests/test_abi.py without a GPU)
+TILE_NAMES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "64x128", 4: "64x64", 5: "S32x32", 6: "S64x32"}
+
 EXPORTS = (["cdx_abi_version", "cdx_strerror", "cdx_launch_count",
-            "cdx_conv_packed_floats", "cdx_conv_pack_weights_f32"]
+            "cdx_conv_packed_floats", "cdx_conv_pack_weights_f32", "cdx_conv_select_tile", "cdx_conv_f32_tile"]
            + [f"cdx_{op}" for op in OPS] + [f"cdx_{op}_workspace" for op in OPS])
 
 _lib = None
@@ -116,6 +118,10 @@ def lib() -> C.CDLL:
     L.cdx_conv_packed_floats.argtypes = [_i, _i, _i, _i]
     L.cdx_conv_pack_weights_f32.restype = C.c_int
     L.cdx_conv_pack_weights_f32.argtypes = [_f, _i, _i, _i, _i, _f]
+    L.cdx_conv_select_tile.restype = C.c_int
+    L.cdx_conv_select_tile.argtypes = [C.POINTER(ConvArgs)]
+    L.cdx_conv_f32_tile.restype = C.c_int
+    L.cdx_conv_f32_tile.argtypes = [C.POINTER(ConvArgs), _i, C.c_void_p, C.c_size_t, C.c_void_p]
     for op, st in OPS.items():
         fn = getattr(L, f"cdx_{op}")
         fn.restype = C.c_int

@@ -4,6 +4,8 @@
 
 #include "conv_kernel.h"
 
+extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, size_t, cdx_stream_t stream);
+
 using namespace cdx;
 
 namespace {
@@ -15,7 +17,7 @@ inline int chunks_of(int c) { return (c + CDX_CONV_KC - 1) / CDX_CONV_KC; }
 extern "C" size_t cdx_conv_packed_floats(int32_t c0, int32_t c1, int32_t cout, int32_t ksize) {
     if (c0 <= 0 || c1 < 0 || cout <= 0 || (ksize != 1 && ksize != 3)) return 0;
     const size_t ntiles = (cout + 31) / 32, nch = chunks_of(c0) + chunks_of(c1);
-    return ntiles * nch * ksize * ksize * 1024 + 1024;   // + one fragment group of tail pad (prefetch overrun)
+    return ntiles * nch * ksize * ksize * 1024 + 4096;   // + 16 KiB tail pad (prefetch-ring overrun)
 }
 
 extern "C" int cdx_conv_pack_weights_f32(const float* w, int32_t c0, int32_t c1, int32_t cout, int32_t ksize,
@@ -40,13 +42,51 @@ extern "C" int cdx_conv_pack_weights_f32(const float* w, int32_t c0, int32_t c1,
                             }
                             *o++ = v;
                         }
-    memset(o, 0, 1024 * sizeof(float));
+    memset(o, 0, 4096 * sizeof(float));
     return CDX_OK;
 }
 
-extern "C" size_t cdx_conv_f32_workspace(const cdx_conv_args*) { return 0; }
+namespace {
 
-extern "C" int cdx_conv_f32(const cdx_conv_args* a, void*, size_t, cdx_stream_t stream) {
+struct Tile { int wcfg, bm, bn; };
+
+constexpr int kSplitKMaxPixels = 256;   // output pixels per image at or below which the split-K tiles are used
+
+Tile tile_of(int wcfg) {
+    switch (wcfg) {
+        case WCFG_1x4x4: return {wcfg, 128, 128};
+        case WCFG_2x2x2: return {wcfg, 128, 64};
+        case WCFG_4x1x1: return {wcfg, 128, 32};
+        case WCFG_1x4x2: return {wcfg, 64, 128};
+        case WCFG_2x2x1: return {wcfg, 64, 64};
+        case WCFG_S32: return {wcfg, 32, 32};
+        case WCFG_S64: return {wcfg, 64, 32};
+        default: return {-1, 0, 0};
+    }
+}
+
+// Tile-shape heuristic.  Depends on the LAYER shape only, never on the batch: a different tile changes the
+// summation order, and an image must decode to the same bits whatever batch / GPU shard it rides in.
+Tile select_tile(const cdx_conv_args* a) {
+    Tile t;
+    if (a->stride == 2) t = tile_of(a->cout <= 64 ? WCFG_2x2x1 : WCFG_1x4x2);
+    else t = tile_of(a->cout <= 32 ? WCFG_4x1x1 : a->cout <= 64 ? WCFG_2x2x2 : WCFG_1x4x4);
+    // Low-resolution levels: 128-pixel tiles would give far fewer workgroups than the chip has CUs (8^2 x
+    // 512 ch at batch 16 = 32 tiles of 128 x 128).  Use 32/64-pixel x 32-channel tiles whose 4 waves split K.
+    if (a->ksize == 3) {
+        const int hw = a->hout * a->wout;
+        if (hw <= kSplitKMaxPixels) t = tile_of(a->stride == 1 && hw >= 256 ? WCFG_S64 : WCFG_S32);
+    }
+    return t;
+}
+
+bool tile_allowed(const cdx_conv_args* a, int wcfg) {
+    if (a->ksize == 1) return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1;
+    if (a->stride == 2) return wcfg == WCFG_1x4x2 || wcfg == WCFG_2x2x1 || wcfg == WCFG_S32;
+    return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1 || wcfg == WCFG_S32 || wcfg == WCFG_S64;
+}
+
+int validate(const cdx_conv_args* a) {
     CDX_REQUIRE(a && a->src0 && a->wpacked && a->out);
     CDX_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c0 % 4) == 0 && (a->c1 % 4) == 0);
     CDX_REQUIRE((a->c1 == 0) == (a->src1 == nullptr));
@@ -60,11 +100,34 @@ extern "C" int cdx_conv_f32(const cdx_conv_args* a, void*, size_t, cdx_stream_t 
     CDX_REQUIRE(a->hout == (a->stride == 1 ? hv : (hv + 1) / 2) && a->wout == (a->stride == 1 ? wv : (wv + 1) / 2));
     CDX_REQUIRE(a->out_ld >= a->cout);
     CDX_REQUIRE(aligned16(a->src0) && aligned16(a->src1) && aligned16(a->wpacked));
-    const bool gn = a->flags & CDX_CONV_GN;
-    if (gn) CDX_REQUIRE(a->gn_scale && a->gn_shift && aligned16(a->gn_scale) && aligned16(a->gn_shift));
+    if (a->flags & CDX_CONV_GN) CDX_REQUIRE(a->gn_scale && a->gn_shift && aligned16(a->gn_scale) && aligned16(a->gn_shift));
     if (a->temb) CDX_REQUIRE(a->temb_ld >= a->cout);
     // 32-bit pixel indexing inside the kernel
     CDX_REQUIRE((int64_t)a->batch * a->hin * a->win < (1ll << 31) && (int64_t)a->batch * a->hout * a->wout < (1ll << 31));
+    return CDX_OK;
+}
+
+}  // namespace
+
+extern "C" size_t cdx_conv_f32_workspace(const cdx_conv_args*) { return 0; }
+
+extern "C" int cdx_conv_select_tile(const cdx_conv_args* a) {
+    const int rc = validate(a);
+    return rc ? rc : select_tile(a).wcfg;
+}
+
+extern "C" int cdx_conv_f32(const cdx_conv_args* a, void* ws, size_t ws_bytes, cdx_stream_t stream) {
+    return cdx_conv_f32_tile(a, -1, ws, ws_bytes, stream);
+}
+
+extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, size_t, cdx_stream_t stream) {
+    int rc = validate(a);
+    if (rc) return rc;
+    const bool experimental = tile >= 16;   // conv_exp.hip: tuning variants of the 128 x 128 tile
+    Tile t = tile < 0 ? select_tile(a) : experimental ? Tile{tile, 128, 128} : tile_of(tile);
+    if (t.wcfg < 0 || (!experimental && !tile_allowed(a, t.wcfg))) return CDX_ENOTSUP;
+    if (experimental && !(a->ksize == 3 && a->stride == 1)) return CDX_ENOTSUP;
+    const int ups = (a->flags & CDX_CONV_UPSAMPLE2X) ? 1 : 0;
 
     ConvParams p;
     p.src[0] = a->src0;
@@ -75,26 +138,19 @@ extern "C" int cdx_conv_f32(const cdx_conv_args* a, void*, size_t, cdx_stream_t 
     p.nchunks = p.nchunk0 + chunks_of(a->c1);
     p.ctot = a->c0 + a->c1;
     p.B = a->batch; p.Hin = a->hin; p.Win = a->win; p.Hout = a->hout; p.Wout = a->wout; p.Cout = a->cout;
-    p.ups = ups; p.gn = gn ? 1 : 0; p.silu = (a->flags & CDX_CONV_SILU) ? 1 : 0;
+    p.ups = ups; p.gn = (a->flags & CDX_CONV_GN) ? 1 : 0; p.silu = (a->flags & CDX_CONV_SILU) ? 1 : 0;
     p.w = a->wpacked; p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift;
     p.temb = a->temb; p.temb_ld = a->temb_ld; p.residual = a->residual; p.out = a->out; p.out_ld = a->out_ld;
 
     const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : a->wout >= 8 ? 3 : 2;
-    int wcfg, bm;
-    if (a->stride == 2) {
-        wcfg = a->cout <= 64 ? WCFG_2x2x1 : WCFG_1x4x2;
-        bm = 64;
-    } else {
-        wcfg = a->cout <= 32 ? WCFG_4x1x1 : a->cout <= 64 ? WCFG_2x2x2 : WCFG_1x4x4;
-        bm = 128;
-    }
-    const int tw = 1 << logtw, th = bm / tw;
+    const int tw = 1 << logtw, th = t.bm / tw;
     p.tiles_x = ceil_div(a->wout, tw);
     p.tiles_y = ceil_div(a->hout, th);
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
 
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (a->ksize == 1) return conv_dispatch_k1s1(logtw, wcfg, p, st);
-    if (a->stride == 1) return conv_dispatch_k3s1(logtw, wcfg, p, st);
-    return conv_dispatch_k3s2(logtw, wcfg, p, st);
+    if (experimental) return conv_dispatch_exp(logtw, t.wcfg, p, st);
+    if (a->ksize == 1) return conv_dispatch_k1s1(logtw, t.wcfg, p, st);
+    if (a->stride == 1) return conv_dispatch_k3s1(logtw, t.wcfg, p, st);
+    return conv_dispatch_k3s2(logtw, t.wcfg, p, st);
 }

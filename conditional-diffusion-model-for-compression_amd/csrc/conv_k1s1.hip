@@ -1,17 +1,18 @@
 // Instantiations of the implicit-GEMM convolution: ksize=1 stride=1.
+// CDX_CONV_CASE(KS, ST, log2(TW), shape id, WM, WN, MT[, WK, PF])
 #include "conv_kernel.h"
 namespace cdx {
 #define CDX_CONV_CASES(KS, ST) \
-    CDX_CONV_CASE(KS, ST, 2, 0, 1, 4, 4) \
+    CDX_CONV_CASE(KS, ST, 2, 0, 1, 4, 4, 1, 4, OPT_OCC2) \
     CDX_CONV_CASE(KS, ST, 2, 1, 2, 2, 2) \
     CDX_CONV_CASE(KS, ST, 2, 2, 4, 1, 1) \
-    CDX_CONV_CASE(KS, ST, 3, 0, 1, 4, 4) \
+    CDX_CONV_CASE(KS, ST, 3, 0, 1, 4, 4, 1, 4, OPT_OCC2) \
     CDX_CONV_CASE(KS, ST, 3, 1, 2, 2, 2) \
     CDX_CONV_CASE(KS, ST, 3, 2, 4, 1, 1) \
-    CDX_CONV_CASE(KS, ST, 4, 0, 1, 4, 4) \
+    CDX_CONV_CASE(KS, ST, 4, 0, 1, 4, 4, 1, 4, OPT_OCC2) \
     CDX_CONV_CASE(KS, ST, 4, 1, 2, 2, 2) \
     CDX_CONV_CASE(KS, ST, 4, 2, 4, 1, 1) \
-    CDX_CONV_CASE(KS, ST, 5, 0, 1, 4, 4) \
+    CDX_CONV_CASE(KS, ST, 5, 0, 1, 4, 4, 1, 4, OPT_OCC2) \
     CDX_CONV_CASE(KS, ST, 5, 1, 2, 2, 2) \
     CDX_CONV_CASE(KS, ST, 5, 2, 4, 1, 1) \
 

@@ -41,9 +41,17 @@ struct ConvParams {
     int tiles_x, tiles_y;
 };
 
-template <int KS_, int STRIDE_, int LOGTW_, int WM_, int WN_, int MT_>
+// WM x WN x WK waves: WM/WN tile the output, WK splits K inside the workgroup (each wave takes every
+// WK-th 8-channel group of every chunk; partial tiles are summed through LDS in fixed order at the end).
+// PF = depth of the weight-fragment prefetch ring, in groups.
+// OPT = tuning switches (A/B-tested in one binary through the experimental tile ids of conv_exp.hip):
+enum { OPT_SPLIT_LDS_READS = 1,  // hide the 16-B alignment: 2 x ds_read2_b32 per fragment instead of ds_read_b128
+       OPT_EXACT_SILU = 2,       // expf + IEEE divide instead of v_exp_f32 + v_rcp_f32
+       OPT_OCC2 = 4,             // __launch_bounds__(256, 2): up to 256 VGPRs, 2 workgroups per CU
+       OPT_STAGGER = 8 };        // delay every second resident workgroup of the first round by ~half a tile
+template <int KS_, int STRIDE_, int LOGTW_, int WM_, int WN_, int MT_, int WK_ = 1, int PF_ = 1, int OPT_ = 0>
 struct ConvCfg {
-    static constexpr int KS = KS_, STRIDE = STRIDE_, LOGTW = LOGTW_, WM = WM_, WN = WN_, MT = MT_;
+    static constexpr int KS = KS_, STRIDE = STRIDE_, LOGTW = LOGTW_, WM = WM_, WN = WN_, MT = MT_, WK = WK_, PF = PF_, OPT = OPT_;
     static constexpr int KC = CDX_CONV_KC, PS = KC + 4;
     static constexpr int TAPS = KS * KS, PAD = KS / 2;
     static constexpr int TW = 1 << LOGTW;
@@ -52,25 +60,35 @@ struct ConvCfg {
     static constexpr int RPM = 32 / TW;  // output rows per 32-pixel MFMA tile
     static constexpr int HH = (TH - 1) * STRIDE + KS, HW = (TW - 1) * STRIDE + KS;
     static constexpr int RS = ((HW * PS + 63) / 64) * 64;
-    static constexpr int LDS_FLOATS = HH * RS;
+    static constexpr int G = 4 / WK;                      // 8-channel groups per (chunk, tap) per wave
+    static constexpr int GPC = KS * KS * G;               // groups per chunk per wave
+    static constexpr int RED_FLOATS = WK > 1 ? 4 * MT * 16 * 64 : 0;   // split-K reduction image
+    static constexpr int LDS_FLOATS = HH * RS > RED_FLOATS ? HH * RS : RED_FLOATS;
     static constexpr int NPIX = HH * HW;
     static constexpr int NPASS = (NPIX + 31) / 32;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(WM * WN * WK == 4, "4 waves per workgroup");
+    static_assert(GPC % PF == 0 && PF <= GPC, "prefetch ring depth must divide the groups per chunk");
     static_assert(TW <= 32 && BM % TW == 0, "tile shape");
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+// x * sigmoid(x) on the transcendental unit: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the ~25-instruction
+// expf + IEEE divide.  |error| <= ~4e-7 * |silu(x)|, the size of one float32 rounding of the result.
+template <bool EXACT>
+__device__ __forceinline__ float silu_f(float v) {
+    if constexpr (EXACT) return v / (1.0f + expf(-v));
+    else return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
+}
 
 template <class C>
-__global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (C::OPT & OPT_OCC2) ? 2 : 3) void conv_kernel(const ConvParams p) {
     constexpr int KC = C::KC, PS = C::PS, RS = C::RS, TAPS = C::TAPS, MT = C::MT, NPASS = C::NPASS;
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int wk = wave % C::WK, wn = (wave / C::WK) % C::WN, wm = wave / (C::WK * C::WN);
 
     int bx = blockIdx.x;
     const int tx = bx % p.tiles_x;
@@ -80,6 +98,17 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
     const int iy0 = oy0 * C::STRIDE - C::PAD, ix0 = ox0 * C::STRIDE - C::PAD;
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+
+    if constexpr (C::OPT & OPT_STAGGER) {
+        // Workgroups that share a CU start together and would run their staging / epilogue phases (no MFMA)
+        // in lockstep.  Offset the second resident set of the first dispatch round so one set's non-MFMA
+        // phases fall under the other's MFMA phases.  Speed only: nothing depends on placement.
+        const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+        if (lin >= 256u && lin < 512u) {
+            const int n = p.nchunks * 2;          // ~ half a tile: nchunks x 36.9k cycles / 2, in 8k-cycle sleeps
+            for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
 
     // ---- loader geometry (chunk independent): thread -> (pixel slot pl, channel quad q) ----
     const int q = tid & 7, pl = tid >> 3;
@@ -130,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
             }
             if (p.silu) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                for (int e = 0; e < 4; ++e) v[e] = silu_f<(C::OPT & OPT_EXACT_SILU) != 0>(v[e]);
             }
             if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (hp < C::NPIX) *reinterpret_cast<f32x4*>(&lds[hy * RS + hx * PS + q * 4]) = v;
@@ -140,11 +169,12 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     // ---- MFMA operand addressing ----
     const int li = lane & 31, lh = lane >> 5;
     const int p0 = wm * MT * 32 + li;                       // pixel of M-tile 0, row li
-    const int a_base = ((p0 >> C::LOGTW) * C::STRIDE) * RS + ((p0 & (C::TW - 1)) * C::STRIDE) * PS + lh * 4;
+    const int a_base = ((p0 >> C::LOGTW) * C::STRIDE) * RS + ((p0 & (C::TW - 1)) * C::STRIDE) * PS + lh * 4 + wk * 8;
     const int ntile = blockIdx.y * C::WN + wn;
     const bool nvalid = ntile * 32 < p.Cout;                // wave-uniform
+    // Packed weights: group (chunk, tap, s) is 1 KiB = 64 lanes x 16 B; this wave uses s = wk + ss*WK.
     const float* __restrict__ wp =
-        p.w + ((size_t)(nvalid ? ntile : 0) * p.nchunks * TAPS) * 1024 + lane * 4;
+        p.w + ((size_t)(nvalid ? ntile : 0) * p.nchunks * TAPS) * 1024 + wk * 256 + lane * 4;
 
     f32x16 acc[MT];
 #pragma unroll
@@ -152,47 +182,79 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // Weight fragments: one 16-B load per lane feeds 4 MFMAs x MT tiles (= one "group" of 16*MT/4
-    // MFMAs, >= 1024 cycles at MT = 4), so prefetching ONE group ahead covers an L2 / MALL hit.
-    // Groups are consecutive 1 KiB pieces of the packed image: index g = (chunk*TAPS + tap)*4 + s.
-    f32x4 bcur = *reinterpret_cast<const f32x4*>(wp);
-    size_t gidx = 0;
+    // Weight fragments: one 16-B load per lane feeds 4 MFMAs x MT tiles (one "group").  A ring of PF
+    // groups is kept in flight; group j of a chunk sits at float offset goff(j) from the chunk base, and
+    // the ring wraps into the next chunk (the packed image carries a 16 KiB tail pad for the overrun).
+    constexpr int G = C::G, GPC = C::GPC, PF = C::PF;
+    auto goff = [](int j) { return ((j / G) * 4 + (j % G) * C::WK) * 256; };
+    f32x4 ring[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) ring[j] = *reinterpret_cast<const f32x4*>(wp + goff(j));
 
+    auto read_a = [&](f32x4 (&a)[MT], int ab, int j) {
+        const int tap = j / G, ss = j % G, ky = tap / C::KS, kx = tap % C::KS;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            a[t] = *reinterpret_cast<const f32x4*>(
+                &lds[ab + (t * C::RPM * C::STRIDE + ky) * RS + kx * PS + ss * C::WK * 8]);
+    };
     issue_loads(0);
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         write_lds();
         __syncthreads();
-        if (chunk + 1 < p.nchunks) issue_loads(chunk + 1);
+        if (chunk + 1 < p.nchunks) issue_loads(chunk + 1);   // lands under this chunk's MFMAs
         if (nvalid) {
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const int ky = tap / C::KS, kx = tap % C::KS;
-                // Opaque copy of the LDS base per tap: M-tile t at tap row ky and M-tile t+1 at row
-                // ky-1 alias when a tile is one image row; without this hipcc keeps the earlier
-                // fragments alive for reuse and spills them to scratch.
+            const float* __restrict__ wc = wp + (size_t)chunk * (TAPS * 1024);
+            f32x4 an[MT];
+            {
                 int ab = a_base;
                 asm volatile("" : "+v"(ab));
+                if constexpr (!(C::OPT & OPT_SPLIT_LDS_READS)) __builtin_assume((ab & 3) == 0);
+                read_a(an, ab, 0);
+            }
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    // the packed image carries a 4 KiB tail pad, so the read past the last group
-                    // stays inside the allocation
-                    ++gidx;
-                    const f32x4 bnxt = *reinterpret_cast<const f32x4*>(wp + gidx * 256);
-                    f32x4 a[MT];
+            for (int j = 0; j < GPC; ++j) {
+                f32x4 a[MT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) a[t] = an[t];
+                if (j + 1 < GPC) {
+                    // Opaque copy of the LDS base per group: M-tile t at tap row ky and M-tile t+1 at row
+                    // ky-1 alias when a tile is one image row; without this hipcc keeps earlier fragments
+                    // alive for reuse and spills them.  The assume keeps the 16-B alignment visible.
+                    int ab = a_base;
+                    asm volatile("" : "+v"(ab));
+                    if constexpr (!(C::OPT & OPT_SPLIT_LDS_READS)) __builtin_assume((ab & 3) == 0);
+                    read_a(an, ab, j + 1);      // next group's fragments land under this group's MFMAs
+                }
+                const f32x4 bcur = ring[j % PF];
+                const int jn = j + PF;                      // refill this ring slot
+                ring[j % PF] = *reinterpret_cast<const f32x4*>(
+                    wc + (jn < GPC ? goff(jn) : TAPS * 1024 + goff(jn - GPC)));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int t = 0; t < MT; ++t)
-                        a[t] = *reinterpret_cast<const f32x4*>(
-                            &lds[ab + (t * C::RPM * C::STRIDE + ky) * RS + kx * PS + s * 8]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int t = 0; t < MT; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][e], bcur[e], acc[t], 0, 0, 0);
-                    bcur = bnxt;
-                }
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][e], bcur[e], acc[t], 0, 0, 0);
             }
         }
         __syncthreads();
+    }
+
+    // ---- split-K: sum the WK partial tiles through LDS (fixed order wk = 0,1,2,3) ----
+    if constexpr (C::WK > 1) {
+        // (the chunk loop ended on a barrier: the halo image is dead)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lds[((wave * MT + t) * 16 + r) * 64 + lane] = acc[t][r];
+        __syncthreads();
+        if (wk != 0) return;
+#pragma unroll
+        for (int k = 1; k < C::WK; ++k)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += lds[(((wave + k) * MT + t) * 16 + r) * 64 + lane];
     }
 
     // ---- epilogue: acc[t][r] is out[pixel (r&3) + 8*(r>>2) + 4*lh of tile t][channel li] ----
@@ -224,19 +286,21 @@ inline int conv_launch(const ConvParams& p, hipStream_t stream) {
     return check_launch();
 }
 
-// wave-layout ids used by the dispatcher
-enum { WCFG_1x4x4 = 0, WCFG_2x2x2 = 1, WCFG_4x1x1 = 2, WCFG_1x4x2 = 3, WCFG_2x2x1 = 4 };
+// tile-shape ids used by the dispatcher (WM x WN x MT [x WK]); the S* shapes split K over the 4 waves
+// and exist for the low-resolution levels, where the big tiles would leave most CUs idle.
+enum { WCFG_1x4x4 = 0, WCFG_2x2x2 = 1, WCFG_4x1x1 = 2, WCFG_1x4x2 = 3, WCFG_2x2x1 = 4, WCFG_S32 = 5, WCFG_S64 = 6 };
 
 int conv_dispatch_k3s1(int logtw, int wcfg, const ConvParams& p, hipStream_t stream);
 int conv_dispatch_k1s1(int logtw, int wcfg, const ConvParams& p, hipStream_t stream);
 int conv_dispatch_k3s2(int logtw, int wcfg, const ConvParams& p, hipStream_t stream);
+int conv_dispatch_exp(int logtw, int wcfg, const ConvParams& p, hipStream_t stream);   // experimental ids >= 16
 
 #define CDX_CONV_DISPATCH_BODY(KS, ST)                                                         \
     switch (wcfg * 8 + logtw) {                                                                \
         CDX_CONV_CASES(KS, ST)                                                                 \
         default: return CDX_ENOTSUP;                                                           \
     }
-#define CDX_CONV_CASE(KS, ST, LT, W, WM, WN, MT) \
-    case (W) * 8 + (LT): return conv_launch<ConvCfg<KS, ST, LT, WM, WN, MT>>(p, stream);
+#define CDX_CONV_CASE(KS, ST, LT, W, ...) \
+    case (W) * 8 + (LT): return conv_launch<ConvCfg<KS, ST, LT, __VA_ARGS__>>(p, stream);
 
 }  // namespace cdx

@@ -75,12 +75,14 @@ def conv(pc: PackedConv, src0, src1=None, **kw):
     hv, wv = (hin * 2, win * 2) if up else (hin, win)
     hout, wout = (hv, wv) if stride == 1 else ((hv + 1) // 2, (wv + 1) // 2)
     out = kw.pop("out", None)
+    tile = kw.pop("tile", -1)        # diagnostics: force a tile shape (cdx.h CDX_TILE_*)
     if out is None:
         out = torch.empty(B, hout, wout, kw.get("out_ld") or pc.cout, device=src0.device, dtype=torch.float32)
         if out.shape[-1] != pc.cout:
             out.zero_()
     a = conv_args(pc, src0, src1, out, **kw)
-    _abi.call("conv_f32", a, None, 0, _stream())
+    import ctypes
+    _abi.check(_abi.lib().cdx_conv_f32_tile(ctypes.byref(a), tile, None, 0, _stream()), "cdx_conv_f32_tile")
     return out
 
 

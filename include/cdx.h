@@ -81,11 +81,28 @@ typedef struct cdx_conv_args {
 int cdx_conv_f32(const cdx_conv_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
 size_t cdx_conv_f32_workspace(const cdx_conv_args* a);
 
+/* Diagnostics / tuning (not needed by a drop-in caller): the tile shape cdx_conv_f32 would pick for `a`
+ * (>= 0, one of CDX_TILE_*; negative = status), and a launch that forces a given shape (CDX_ENOTSUP if the
+ * shape is not built for that ksize/stride).  Tests use these to cover every instantiation; bench.py uses
+ * the first to name the dominant kernel. */
+enum {
+    CDX_TILE_128x128 = 0, /* 4 waves 1x4, 4 M-tiles each            */
+    CDX_TILE_128x64 = 1,  /* 2x2, 2 M-tiles                         */
+    CDX_TILE_128x32 = 2,  /* 4x1, 1 M-tile (cout <= 32)             */
+    CDX_TILE_64x128 = 3,  /* stride 2: 1x4, 2 M-tiles               */
+    CDX_TILE_64x64 = 4,   /* stride 2: 2x2, 1 M-tile                */
+    CDX_TILE_S32x32 = 5,  /* low-resolution levels: 4 waves split K */
+    CDX_TILE_S64x32 = 6
+};
+int cdx_conv_select_tile(const cdx_conv_args* a);
+int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+
 /* HOST helper: number of floats of the packed weight image, and the packer.
  * w_oihw: host [cout][c0+c1][ksize][ksize] (torch layout).  Packed layout:
  *   [ntile = ceil(cout/32)][chunk][tap = ky*ksize+kx][s = 0..3][lane = 0..63][e = 0..3]
  *   = W[n = 32*ntile + (lane&31)][c = chunk_base + 8*s + 4*(lane>>5) + e][ky][kx]
- * chunks: ceil(c0/32) of src0 then ceil(c1/32) of src1, zero-filled past each source's end. */
+ * chunks: ceil(c0/32) of src0 then ceil(c1/32) of src1, zero-filled past each source's end; the image ends
+ * with a 16 KiB zero pad (the kernels' weight prefetch ring reads past the last fragment). */
 size_t cdx_conv_packed_floats(int32_t c0, int32_t c1, int32_t cout, int32_t ksize);
 int cdx_conv_pack_weights_f32(const float* w_oihw, int32_t c0, int32_t c1, int32_t cout,
                               int32_t ksize, float* packed);

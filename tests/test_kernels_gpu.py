@@ -56,6 +56,13 @@ CONV_CASES = [
 ]
 
 
+def tiles_for(k, s):
+    """Every tile shape built for this ksize / stride (include/cdx.h CDX_TILE_*), plus -1 = the library's pick."""
+    if k == 1:
+        return (-1, 0, 1, 2)
+    return (-1, 3, 4, 5) if s == 2 else (-1, 0, 1, 2, 5, 6)
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_plain(cdx_mod, case):
     B, ci, co, H, W, k, s, up = case
@@ -65,9 +72,11 @@ def test_conv_plain(cdx_mod, case):
     xin = F.interpolate(x.double(), scale_factor=2, mode="nearest") if up else x.double()
     want = F.conv2d(xin, w.double(), bias.double(), stride=s, padding=k // 2)
     pc = cdx_mod.ops.PackedConv(w.numpy(), bias.numpy(), ci)
-    got = nchw(cdx_mod.ops.conv(pc, nhwc(x), stride=s, upsample=up))
-    assert got.shape == want.shape
-    close(got, want, 2e-6, "conv")
+    xd = nhwc(x)
+    for tile in tiles_for(k, s):
+        got = nchw(cdx_mod.ops.conv(pc, xd, stride=s, upsample=up, tile=tile))
+        assert got.shape == want.shape
+        close(got, want, 2e-6, f"conv tile {tile}")
 
 
 @pytest.mark.parametrize("B,c0,c1,co,H,W,groups", [
@@ -97,8 +106,9 @@ def test_conv_fused_gn_silu_concat_temb_residual(cdx_mod, B, c0, c1, co, H, W, g
     close(mean.cpu(), xg.mean(-1), 1e-6, "gn mean")
     close(rstd.cpu(), (xg.var(-1, unbiased=False) + 1e-5).rsqrt(), 1e-6, "gn rstd")
     pc = ops.PackedConv(w.numpy(), bias.numpy(), c0, c1)
-    got = nchw(ops.conv(pc, s0, s1, gn=(sc, sh), silu=True, temb=temb.cuda(), temb_off=2, residual=nhwc(res)))
-    close(got, want, 3e-6, "fused conv")
+    for tile in tiles_for(3, 1):
+        got = nchw(ops.conv(pc, s0, s1, gn=(sc, sh), silu=True, temb=temb.cuda(), temb_off=2, residual=nhwc(res), tile=tile))
+        close(got, want, 3e-6, f"fused conv tile {tile}")
 
 
 def test_gn_no_silu_1x1(cdx_mod):
