@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcdx.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 CONV_UPSAMPLE2X, CONV_GN, CONV_SILU = 1, 2, 4
 LINEAR_SILU_IN = 1
 CONV_KC = 32
@@ -25,12 +25,18 @@ class ConvArgs(C.Structure):
                 ("batch", _i), ("hin", _i), ("win", _i), ("hout", _i), ("wout", _i),
                 ("cout", _i), ("ksize", _i), ("stride", _i), ("flags", _i),
                 ("wpacked", _f), ("bias", _f), ("gn_scale", _f), ("gn_shift", _f),
-                ("temb", _f), ("temb_ld", _i), ("residual", _f), ("out", _f), ("out_ld", _i)]
+                ("temb", _f), ("temb_ld", _i), ("residual", _f), ("out", _f), ("out_ld", _i), ("stats_out", _f)]
 
 
 class GnStatsArgs(C.Structure):
     _fields_ = [("src0", _f), ("src1", _f), ("c0", _i), ("c1", _i), ("batch", _i), ("hw", _i),
                 ("groups", _i), ("eps", C.c_float), ("gamma", _f), ("beta", _f),
+                ("scale", _f), ("shift", _f), ("mean", _f), ("rstd", _f)]
+
+
+class GnFinalizeArgs(C.Structure):
+    _fields_ = [("part0", _f), ("slots0", _i), ("c0", _i), ("part1", _f), ("slots1", _i), ("c1", _i),
+                ("batch", _i), ("hw", _i), ("groups", _i), ("eps", C.c_float), ("gamma", _f), ("beta", _f),
                 ("scale", _f), ("shift", _f), ("mean", _f), ("rstd", _f)]
 
 
@@ -76,6 +82,7 @@ class ExportImageArgs(C.Structure):
 OPS = {
     "conv_f32": ConvArgs,
     "gn_stats_f32": GnStatsArgs,
+    "gn_finalize_f32": GnFinalizeArgs,
     "attn_f32": AttnArgs,
     "linear_f32": LinearArgs,
     "timestep_embedding_f32": TimestepEmbeddingArgs,
@@ -89,7 +96,8 @@ OPS = {
 TILE_NAMES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "64x128", 4: "64x64", 5: "S32x32", 6: "S64x32"}
 
 EXPORTS = (["cdx_abi_version", "cdx_strerror", "cdx_launch_count",
-            "cdx_conv_packed_floats", "cdx_conv_pack_weights_f32", "cdx_conv_select_tile", "cdx_conv_f32_tile"]
+            "cdx_conv_packed_floats", "cdx_conv_pack_weights_f32", "cdx_conv_select_tile", "cdx_conv_f32_tile",
+            "cdx_conv_stats_slots"]
            + [f"cdx_{op}" for op in OPS] + [f"cdx_{op}_workspace" for op in OPS])
 
 _lib = None
@@ -120,6 +128,8 @@ def lib() -> C.CDLL:
     L.cdx_conv_pack_weights_f32.argtypes = [_f, _i, _i, _i, _i, _f]
     L.cdx_conv_select_tile.restype = C.c_int
     L.cdx_conv_select_tile.argtypes = [C.POINTER(ConvArgs)]
+    L.cdx_conv_stats_slots.restype = C.c_int32
+    L.cdx_conv_stats_slots.argtypes = [C.POINTER(ConvArgs)]
     L.cdx_conv_f32_tile.restype = C.c_int
     L.cdx_conv_f32_tile.argtypes = [C.POINTER(ConvArgs), _i, C.c_void_p, C.c_size_t, C.c_void_p]
     for op, st in OPS.items():

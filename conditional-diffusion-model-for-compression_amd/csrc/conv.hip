@@ -48,20 +48,20 @@ extern "C" int cdx_conv_pack_weights_f32(const float* w, int32_t c0, int32_t c1,
 
 namespace {
 
-struct Tile { int wcfg, bm, bn; };
+struct Tile { int wcfg, bm, bn, wm; };
 
 constexpr int kSplitKMaxPixels = 256;   // output pixels per image at or below which the split-K tiles are used
 
 Tile tile_of(int wcfg) {
     switch (wcfg) {
-        case WCFG_1x4x4: return {wcfg, 128, 128};
-        case WCFG_2x2x2: return {wcfg, 128, 64};
-        case WCFG_4x1x1: return {wcfg, 128, 32};
-        case WCFG_1x4x2: return {wcfg, 64, 128};
-        case WCFG_2x2x1: return {wcfg, 64, 64};
-        case WCFG_S32: return {wcfg, 32, 32};
-        case WCFG_S64: return {wcfg, 64, 32};
-        default: return {-1, 0, 0};
+        case WCFG_1x4x4: return {wcfg, 128, 128, 1};
+        case WCFG_2x2x2: return {wcfg, 128, 64, 2};
+        case WCFG_4x1x1: return {wcfg, 128, 32, 4};
+        case WCFG_1x4x2: return {wcfg, 64, 128, 1};
+        case WCFG_2x2x1: return {wcfg, 64, 64, 2};
+        case WCFG_S32: return {wcfg, 32, 32, 1};
+        case WCFG_S64: return {wcfg, 64, 32, 1};
+        default: return {-1, 0, 0, 0};
     }
 }
 
@@ -116,6 +116,14 @@ extern "C" int cdx_conv_select_tile(const cdx_conv_args* a) {
     return rc ? rc : select_tile(a).wcfg;
 }
 
+extern "C" int32_t cdx_conv_stats_slots(const cdx_conv_args* a) {
+    if (validate(a)) return 0;
+    const Tile t = select_tile(a);
+    const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : a->wout >= 8 ? 3 : 2;
+    const int tw = 1 << logtw, th = t.bm / tw;
+    return ceil_div(a->wout, tw) * ceil_div(a->hout, th) * t.wm;
+}
+
 extern "C" int cdx_conv_f32(const cdx_conv_args* a, void* ws, size_t ws_bytes, cdx_stream_t stream) {
     return cdx_conv_f32_tile(a, -1, ws, ws_bytes, stream);
 }
@@ -124,7 +132,7 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
     int rc = validate(a);
     if (rc) return rc;
     const bool experimental = tile >= 16;   // conv_exp.hip: tuning variants of the 128 x 128 tile
-    Tile t = tile < 0 ? select_tile(a) : experimental ? Tile{tile, 128, 128} : tile_of(tile);
+    Tile t = tile < 0 ? select_tile(a) : experimental ? Tile{tile, 128, 128, 1} : tile_of(tile);
     if (t.wcfg < 0 || (!experimental && !tile_allowed(a, t.wcfg))) return CDX_ENOTSUP;
     if (experimental && !(a->ksize == 3 && a->stride == 1)) return CDX_ENOTSUP;
     const int ups = (a->flags & CDX_CONV_UPSAMPLE2X) ? 1 : 0;
@@ -141,6 +149,8 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
     p.ups = ups; p.gn = (a->flags & CDX_CONV_GN) ? 1 : 0; p.silu = (a->flags & CDX_CONV_SILU) ? 1 : 0;
     p.w = a->wpacked; p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift;
     p.temb = a->temb; p.temb_ld = a->temb_ld; p.residual = a->residual; p.out = a->out; p.out_ld = a->out_ld;
+    p.stats = a->stats_out;
+    if (a->stats_out && tile >= 0) return CDX_EINVAL;   // slot count is defined for the library's own tile choice
 
     const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : a->wout >= 8 ? 3 : 2;
     const int tw = 1 << logtw, th = t.bm / tw;

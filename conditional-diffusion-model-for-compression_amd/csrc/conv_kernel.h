@@ -38,6 +38,7 @@ struct ConvParams {
     const float* residual;
     float* out;
     int out_ld;
+    double* stats;   // [B][tiles_y*tiles_x*WM][Cout][2] or nullptr
     int tiles_x, tiles_y;
 };
 
@@ -260,21 +261,41 @@ __global__ __launch_bounds__(256, (C::OPT & OPT_OCC2) ? 2 : 3) void conv_kernel(
     // ---- epilogue: acc[t][r] is out[pixel (r&3) + 8*(r>>2) + 4*lh of tile t][channel li] ----
     if (!nvalid) return;
     const int n = ntile * 32 + li;
-    if (n >= p.Cout) return;
-    float add = p.bias ? p.bias[n] : 0.f;
-    if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
+    const bool nok = n < p.Cout;
+    float add = 0.f;
+    if (nok) {
+        add = p.bias ? p.bias[n] : 0.f;
+        if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
+    }
+    double s1 = 0.0, s2 = 0.0;      // per-channel sum / sum of squares of the stored values (GroupNorm of `out`)
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (wm * MT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int oy = oy0 + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
-            if (oy < p.Hout && ox < p.Wout) {
+            if (nok && oy < p.Hout && ox < p.Wout) {
                 const size_t pix = ((size_t)b * p.Hout + oy) * p.Wout + ox;
                 float v = acc[t][r] + add;
                 if (p.residual) v += p.residual[pix * p.Cout + n];
                 p.out[pix * p.out_ld + n] = v;
+                if (p.stats) {
+                    const double d = (double)v;
+                    s1 += d;
+                    s2 = fma(d, d, s2);
+                }
             }
+        }
+    }
+    if (p.stats) {      // wave-uniform
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lh == 0 && nok) {
+            const int slot = (ty * p.tiles_x + tx) * C::WM + wm;
+            const int nslots = p.tiles_y * p.tiles_x * C::WM;
+            double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + n) * 2;
+            o[0] = s1;
+            o[1] = s2;
         }
     }
 }

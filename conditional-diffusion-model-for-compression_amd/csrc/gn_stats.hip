@@ -111,7 +111,70 @@ __global__ __launch_bounds__(64) void gn_finalize(const double* __restrict__ par
     }
 }
 
+// Fused form: partial sums were left by the producing convolutions (conv_kernel epilogue), one slot per
+// (spatial tile, wave row); the two sources of a channel concat each bring their own slot count.
+__global__ __launch_bounds__(64) void gn_finalize2(const double* __restrict__ part0, int slots0, int c0,
+                                                   const double* __restrict__ part1, int slots1, int c1, int groups,
+                                                   int hw, float eps, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float* __restrict__ scale,
+                                                   float* __restrict__ shift, float* __restrict__ mean_out,
+                                                   float* __restrict__ rstd_out) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int ctot = c0 + c1, cpg = ctot / groups;
+    const int cbeg = g * cpg, cend = cbeg + cpg;
+    double s = 0, ss = 0;
+    // channels of this group that live in source 0 / source 1
+    const int n0 = max(0, min(cend, c0) - cbeg), n1 = cpg - n0;
+    for (int it = lane; it < slots0 * n0; it += 64) {
+        const int slot = it / n0, c = cbeg + it % n0;
+        const double* q = part0 + (((size_t)b * slots0 + slot) * c0 + c) * 2;
+        s += q[0];
+        ss += q[1];
+    }
+    for (int it = lane; it < slots1 * n1; it += 64) {
+        const int slot = it / n1, c = max(cbeg, c0) - c0 + it % n1;
+        const double* q = part1 + (((size_t)b * slots1 + slot) * c1 + c) * 2;
+        s += q[0];
+        ss += q[1];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s += __shfl_xor(s, off);
+        ss += __shfl_xor(ss, off);
+    }
+    const double n = (double)hw * cpg;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    var = var < 0 ? 0 : var;
+    const float meanf = (float)mean;
+    const float rstdf = (float)(1.0 / sqrt(var + (double)eps));
+    if (lane == 0) {
+        if (mean_out) mean_out[b * groups + g] = meanf;
+        if (rstd_out) rstd_out[b * groups + g] = rstdf;
+    }
+    for (int k = lane; k < cpg; k += 64) {
+        const int c = cbeg + k;
+        const float sc = rstdf * gamma[c];
+        scale[(size_t)b * ctot + c] = sc;
+        shift[(size_t)b * ctot + c] = -sc * meanf + beta[c];
+    }
+}
+
 }  // namespace
+
+extern "C" size_t cdx_gn_finalize_f32_workspace(const cdx_gn_finalize_args*) { return 0; }
+
+extern "C" int cdx_gn_finalize_f32(const cdx_gn_finalize_args* a, void*, size_t, cdx_stream_t stream) {
+    CDX_REQUIRE(a && a->part0 && a->gamma && a->beta && a->scale && a->shift);
+    CDX_REQUIRE(a->c0 > 0 && a->slots0 > 0 && a->c1 >= 0);
+    CDX_REQUIRE((a->c1 == 0) == (a->part1 == nullptr));
+    if (a->c1) CDX_REQUIRE(a->slots1 > 0);
+    CDX_REQUIRE(a->batch > 0 && a->batch <= 65535 && a->hw > 0 && a->groups > 0 && (a->c0 + a->c1) % a->groups == 0);
+    hipLaunchKernelGGL(gn_finalize2, dim3(a->groups, a->batch), dim3(64), 0, static_cast<hipStream_t>(stream), a->part0,
+                       a->slots0, a->c0, a->part1, a->slots1, a->c1, a->groups, a->hw, a->eps, a->gamma, a->beta, a->scale,
+                       a->shift, a->mean, a->rstd);
+    return check_launch();
+}
 
 extern "C" size_t cdx_gn_stats_f32_workspace(const cdx_gn_stats_args* a) {
     if (!a || a->batch <= 0 || a->hw <= 0) return 0;

@@ -44,7 +44,7 @@ class PackedConv:
 
 
 def conv_args(pc: PackedConv, src0, src1, out, *, stride=1, upsample=False, gn=None, silu=False,
-              temb=None, temb_off=0, temb_ld=0, residual=None, out_ld=None) -> _abi.ConvArgs:
+              temb=None, temb_off=0, temb_ld=0, residual=None, out_ld=None, stats=None) -> _abi.ConvArgs:
     B, hin, win, c0 = src0.shape
     assert c0 == pc.c0 and (src1 is None) == (pc.c1 == 0)
     if src1 is not None:
@@ -65,7 +65,44 @@ def conv_args(pc: PackedConv, src0, src1, out, *, stride=1, upsample=False, gn=N
     a.residual = _ptr(residual)
     a.out, a.out_ld = _ptr(out), out_ld or out.shape[-1]
     assert out.shape[0] == B and out.shape[1] == hout and out.shape[2] == wout and a.out_ld >= pc.cout
+    if stats is not None:          # float64 [B, slots, cout, 2] partial sums for gn_finalize (see conv_stats_buffer)
+        assert stats.dtype == torch.float64 and stats.is_contiguous()
+        a.stats_out = stats.data_ptr()
     return a
+
+
+def conv_stats_buffer(a: _abi.ConvArgs, device) -> torch.Tensor:
+    """Allocate the stats_out buffer the library wants for this launch and attach it to the args."""
+    import ctypes
+    slots = _abi.lib().cdx_conv_stats_slots(ctypes.byref(a))
+    if slots <= 0:
+        raise _abi.CdxError("cdx_conv_stats_slots: bad arguments")
+    buf = torch.zeros(a.batch, slots, a.cout, 2, dtype=torch.float64, device=device)
+    a.stats_out = buf.data_ptr()
+    return buf
+
+
+def gn_finalize_args(stats0, stats1, hw, gamma, beta, groups, scale, shift, eps=1e-5, mean=None, rstd=None):
+    a = _abi.GnFinalizeArgs()
+    a.part0, a.slots0, a.c0 = stats0.data_ptr(), stats0.shape[1], stats0.shape[2]
+    if stats1 is not None:
+        a.part1, a.slots1, a.c1 = stats1.data_ptr(), stats1.shape[1], stats1.shape[2]
+    a.batch, a.hw, a.groups, a.eps = stats0.shape[0], hw, groups, eps
+    a.gamma, a.beta, a.scale, a.shift = _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift)
+    a.mean, a.rstd = _ptr(mean), _ptr(rstd)
+    return a
+
+
+def gn_finalize(stats0, stats1, hw, gamma, beta, groups, eps=1e-5, want_moments=False):
+    B = stats0.shape[0]
+    C = stats0.shape[2] + (0 if stats1 is None else stats1.shape[2])
+    dev = stats0.device
+    scale, shift = torch.empty(B, C, device=dev), torch.empty(B, C, device=dev)
+    mean = torch.empty(B, groups, device=dev) if want_moments else None
+    rstd = torch.empty(B, groups, device=dev) if want_moments else None
+    _abi.call("gn_finalize_f32", gn_finalize_args(stats0, stats1, hw, gamma, beta, groups, scale, shift, eps, mean, rstd),
+              None, 0, _stream())
+    return (scale, shift, mean, rstd) if want_moments else (scale, shift)
 
 
 def conv(pc: PackedConv, src0, src1=None, **kw):
@@ -80,10 +117,12 @@ def conv(pc: PackedConv, src0, src1=None, **kw):
         out = torch.empty(B, hout, wout, kw.get("out_ld") or pc.cout, device=src0.device, dtype=torch.float32)
         if out.shape[-1] != pc.cout:
             out.zero_()
+    want_stats = kw.pop("want_stats", False)
     a = conv_args(pc, src0, src1, out, **kw)
+    stats = conv_stats_buffer(a, src0.device) if want_stats else None
     import ctypes
     _abi.check(_abi.lib().cdx_conv_f32_tile(ctypes.byref(a), tile, None, 0, _stream()), "cdx_conv_f32_tile")
-    return out
+    return (out, stats) if want_stats else out
 
 
 def gn_stats_args(src0, src1, gamma, beta, groups, scale, shift, eps=1e-5, mean=None, rstd=None) -> _abi.GnStatsArgs:

@@ -53,11 +53,21 @@ class _Plan:
         self._add("linear_f32", ops.linear_args(emb1, net.dev["temb.2.weight"], net.dev["temb.2.bias"], emb2, silu_in=True))
         self._add("linear_f32", ops.linear_args(emb2, net.tproj_w, net.tproj_b, self.tproj, silu_in=True))
 
+        stats_of = {}            # data_ptr of a conv output -> its fused partial-sum buffer
+
         def gn(name, src0, src1=None):
+            """scale/shift of GroupNorm(cat[src0, src1]).  When every source was written by one of our convs the
+            sums come from that conv's epilogue (cdx_gn_finalize_f32: no extra pass over the activation)."""
             c = src0.shape[-1] + (0 if src1 is None else src1.shape[-1])
             sc, sh = new(B, c), new(B, c)
-            a = ops.gn_stats_args(src0, src1, net.dev[name + ".weight"], net.dev[name + ".bias"], cfg["groups"], sc, sh)
-            self._add("gn_stats_f32", a, ws=True)
+            gamma, beta = net.dev[name + ".weight"], net.dev[name + ".bias"]
+            st0 = stats_of.get(src0.data_ptr())
+            st1 = None if src1 is None else stats_of.get(src1.data_ptr())
+            if net.fuse_gn_stats and st0 is not None and (src1 is None or st1 is not None):
+                hw = src0.shape[1] * src0.shape[2]
+                self._add("gn_finalize_f32", ops.gn_finalize_args(st0, st1, hw, gamma, beta, cfg["groups"], sc, sh))
+            else:
+                self._add("gn_stats_f32", ops.gn_stats_args(src0, src1, gamma, beta, cfg["groups"], sc, sh), ws=True)
             return sc, sh
 
         def conv(name, src0, src1=None, **kw):
@@ -66,21 +76,25 @@ class _Plan:
             hv, wv = (2 * hin, 2 * win) if kw.get("upsample") else (hin, win)
             s = kw.get("stride", 1)
             out = kw.pop("out", None)
+            normed_later = kw.pop("normed_later", False)     # a GroupNorm will read this output
             if out is None:
                 out = new(Bn, (hv + s - 1) // s, (wv + s - 1) // s, pc.cout)
-            self._add("conv_f32", ops.conv_args(pc, src0, src1, out, **kw))
+            a = ops.conv_args(pc, src0, src1, out, **kw)
+            if normed_later and net.fuse_gn_stats:
+                stats_of[out.data_ptr()] = self._hold(ops.conv_stats_buffer(a, dev))
+            self._add("conv_f32", a)
             return out
 
         def res(blk, x, skip=None):
             n = blk.name
-            h1 = conv(n + ".conv1", x, skip, gn=gn(n + ".norm1", x, skip), silu=True,
+            h1 = conv(n + ".conv1", x, skip, gn=gn(n + ".norm1", x, skip), silu=True, normed_later=True,
                       temb=self.tproj, temb_off=net.tproj_off[n], temb_ld=self.tproj.shape[-1])
             if blk.cin != blk.cout:
                 r = conv(n + ".skip", x, skip)
             else:
                 assert skip is None
                 r = x
-            return conv(n + ".conv2", h1, gn=gn(n + ".norm2", h1), silu=True, residual=r)
+            return conv(n + ".conv2", h1, gn=gn(n + ".norm2", h1), silu=True, residual=r, normed_later=True)
 
         def attn(blk, x):
             n = blk.name
@@ -90,7 +104,7 @@ class _Plan:
             self._add("attn_f32", ops.attn_args(qkv, qkv, qkv, o, batch=Bn, nq=hh * ww, nk=hh * ww,
                                                  heads=c // cfg["head_dim"], head_dim=cfg["head_dim"],
                                                  q_ld=3 * c, k_ld=3 * c, v_ld=3 * c, out_ld=c, k_off=c, v_off=2 * c))
-            return conv(n + ".proj", o, residual=x)
+            return conv(n + ".proj", o, residual=x, normed_later=True)
 
         def xattn(blk, x):
             n = blk.name
@@ -102,7 +116,7 @@ class _Plan:
             self._add("attn_f32", ops.attn_args(q, kv, kv, o, batch=Bn, nq=hh * ww, nk=L,
                                                  heads=c // cfg["head_dim"], head_dim=cfg["head_dim"],
                                                  q_ld=c, k_ld=2 * c, v_ld=2 * c, out_ld=c, v_off=c))
-            return conv(n + ".proj", o, residual=x)
+            return conv(n + ".proj", o, residual=x, normed_later=True)
 
         def run_block(blk, h, skip=None):
             if blk.kind == "res":
@@ -112,9 +126,9 @@ class _Plan:
             if blk.kind == "xattn":
                 return xattn(blk, h)
             if blk.kind == "down":
-                return conv(blk.name, h, stride=2)
+                return conv(blk.name, h, stride=2, normed_later=True)
             if blk.kind == "up":
-                return conv(blk.name, h, upsample=True)
+                return conv(blk.name, h, upsample=True, normed_later=True)
             raise ValueError(blk.kind)
 
         if cross:
@@ -122,7 +136,7 @@ class _Plan:
             lw = 32 if L % 32 == 0 else L
             self.ctx = self._hold(torch.zeros(B, L // lw, lw, D, device=dev))
 
-        h = conv("conv_in", self.xin)
+        h = conv("conv_in", self.xin, normed_later=True)
         skips = [h]
         for blk in g.down:
             h = run_block(blk, h)
@@ -168,8 +182,10 @@ class _Plan:
 class UNet:
     """unet = UNet(cfg_dict[, params]); eps = unet.forward(x, t, cond)."""
 
-    def __init__(self, cfg: dict, params: dict | None = None, *, seed: int = 0, device="cuda"):
+    def __init__(self, cfg: dict, params: dict | None = None, *, seed: int = 0, device="cuda",
+                 fuse_gn_stats: bool = True):
         _abi.lib()   # fail loudly now if the extension is missing
+        self.fuse_gn_stats = fuse_gn_stats   # False: every GroupNorm re-reads its input (cdx_gn_stats_f32)
         if not torch.cuda.is_available():
             raise RuntimeError("UNet (HIP backend) needs a GPU; there is no CPU fallback in the product path")
         self.cfg = validate_unet_config(cfg)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 1
+#define CDX_ABI_VERSION 2
 
 typedef void* cdx_stream_t; /* hipStream_t */
 
@@ -76,10 +76,15 @@ typedef struct cdx_conv_args {
     const float* residual; /* [batch, hout, wout, cout] or NULL: out += residual */
     float* out;            /* [batch, hout, wout, out_ld], channels [0, cout) written */
     int32_t out_ld;
+    double* stats_out;     /* NULL, or [batch, cdx_conv_stats_slots(a), cout, 2]: per-slot (sum, sum of squares) of the
+                              values stored to `out`, float64, for cdx_gn_finalize_f32 (GroupNorm of `out` without
+                              re-reading it) */
 } cdx_conv_args;
 
 int cdx_conv_f32(const cdx_conv_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
 size_t cdx_conv_f32_workspace(const cdx_conv_args* a);
+/* HOST: number of partial-sum slots per image cdx_conv_f32 writes to stats_out for this launch (0 on bad args). */
+int32_t cdx_conv_stats_slots(const cdx_conv_args* a);
 
 /* Diagnostics / tuning (not needed by a drop-in caller): the tile shape cdx_conv_f32 would pick for `a`
  * (>= 0, one of CDX_TILE_*; negative = status), and a launch that forces a given shape (CDX_ENOTSUP if the
@@ -129,6 +134,25 @@ typedef struct cdx_gn_stats_args {
 
 int cdx_gn_stats_f32(const cdx_gn_stats_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
 size_t cdx_gn_stats_f32_workspace(const cdx_gn_stats_args* a);
+
+/* U2, fused form: the same scale / shift from partial sums that the producing convolutions left in their
+ * stats_out buffers (one or two sources = channel concat).  Sums the slots in fixed order in float64. */
+typedef struct cdx_gn_finalize_args {
+    const double* part0; int32_t slots0; int32_t c0; /* [batch, slots0, c0, 2] */
+    const double* part1; int32_t slots1; int32_t c1; /* [batch, slots1, c1, 2] or NULL / 0 / 0 */
+    int32_t batch, hw;                               /* hw = pixels per image of the normalised tensor */
+    int32_t groups;
+    float eps;
+    const float* gamma; /* [c0+c1] */
+    const float* beta;
+    float* scale;       /* [batch, c0+c1] */
+    float* shift;
+    float* mean;        /* [batch, groups] or NULL */
+    float* rstd;
+} cdx_gn_finalize_args;
+
+int cdx_gn_finalize_f32(const cdx_gn_finalize_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_gn_finalize_f32_workspace(const cdx_gn_finalize_args* a);
 
 /* ------------------------------------------------------------------------------------------
  * U6/U7: multi-head attention core  out = softmax(q k^T * scale) v  on fp32 MFMA.

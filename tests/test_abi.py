@@ -22,14 +22,14 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(cdx._abi.EXPORTS), declared ^ set(cdx._abi.EXPORTS)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.cdx_abi_version() == 1
+    assert lib.cdx_abi_version() == 2
     assert b"workspace" in lib.cdx_strerror(-2) and lib.cdx_strerror(0) == b"ok"
 
 
 def test_struct_layouts_match_c(tmp_path):
     """Compile a C program that prints sizeof/offsetof for every args struct and compare with ctypes."""
     A = cdx._abi
-    structs = {"cdx_conv_args": A.ConvArgs, "cdx_gn_stats_args": A.GnStatsArgs, "cdx_attn_args": A.AttnArgs,
+    structs = {"cdx_conv_args": A.ConvArgs, "cdx_gn_stats_args": A.GnStatsArgs, "cdx_gn_finalize_args": A.GnFinalizeArgs, "cdx_attn_args": A.AttnArgs,
                "cdx_linear_args": A.LinearArgs, "cdx_timestep_embedding_args": A.TimestepEmbeddingArgs,
                "cdx_diffusion_update_args": A.DiffusionUpdateArgs, "cdx_gauss_fill_args": A.GaussFillArgs,
                "cdx_cond_embed_args": A.CondEmbedArgs, "cdx_export_image_args": A.ExportImageArgs}

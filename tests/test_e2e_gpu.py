@@ -107,6 +107,18 @@ def test_sampler_cfg1_golden(cdx_mod, record):
     assert got.abs().max().item() <= 1.0
 
 
+def test_fused_and_standalone_groupnorm_paths_agree(cdx_mod):
+    """UNet with GroupNorm sums taken from conv epilogues vs the same UNet re-reading every tensor."""
+    cfg = cdx_mod.unet_config(image_size=32, base_channels=64, channel_mult=(1, 2, 2), attn_resolutions=(16,), num_res_blocks=1)
+    params = cdx_mod.init_params(cfg, seed=8, affine_jitter=0.1, out_gain=1.0)
+    cond = torch.from_numpy(cdx_mod.synthetic_batch(cfg, 8, 0, 2)["cond"]).cuda()
+    x = torch.randn(2, 3, 32, 32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+    t = torch.tensor([700, 20], device="cuda")
+    a = cdx_mod.UNet(cfg, params, fuse_gn_stats=True).forward(x, t, cond)
+    b = cdx_mod.UNet(cfg, params, fuse_gn_stats=False).forward(x, t, cond)
+    assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())
+
+
 def test_sampler_ddpm_golden(cdx_mod, record):
     """Ancestral sampling (fresh device noise every step) against the committed oracle output."""
     g = np.load(os.path.join(GOLD, "tiny_ddpm.npz"))

@@ -111,6 +111,32 @@ def test_conv_fused_gn_silu_concat_temb_residual(cdx_mod, B, c0, c1, co, H, W, g
         close(got, want, 3e-6, f"fused conv tile {tile}")
 
 
+@pytest.mark.parametrize("B,ci,c_a,c_b,H,W,k,s", [(2, 32, 64, 32, 32, 32, 3, 1), (1, 64, 128, 0, 16, 16, 3, 1), (2, 32, 96, 64, 8, 8, 1, 1),
+                                                   (2, 32, 64, 0, 40, 24, 3, 2), (3, 32, 32, 32, 4, 4, 3, 1), (1, 32, 160, 0, 64, 64, 3, 1)])
+def test_conv_epilogue_stats_match_standalone_gn(cdx_mod, B, ci, c_a, c_b, H, W, k, s):
+    """GroupNorm statistics accumulated in the producing convs' epilogues (one or two producers = concat) give the
+    same scale/shift as the standalone pass over the stored tensors, and as float64 torch."""
+    ops = cdx_mod.ops
+    x = nhwc(rnd(B, ci, H, W, seed=60))
+    outs, stats = [], []
+    for j, co in enumerate([c for c in (c_a, c_b) if c]):
+        w = rnd(co, ci, k, k, seed=61 + j, scale=1.0 / math.sqrt(ci * k * k))
+        pc = ops.PackedConv(w.numpy(), rnd(co, seed=63 + j).numpy() + 3.0, ci)      # biased: non-zero mean
+        o, st = ops.conv(pc, x, stride=s, want_stats=True)
+        outs.append(o)
+        stats.append(st)
+    C = c_a + c_b
+    gamma, beta = (1 + 0.2 * rnd(C, seed=65)).cuda(), (0.3 * rnd(C, seed=66)).cuda()
+    hw = outs[0].shape[1] * outs[0].shape[2]
+    o1 = outs[1] if c_b else None
+    sc_f, sh_f, m_f, r_f = ops.gn_finalize(stats[0], stats[1] if c_b else None, hw, gamma, beta, 32, want_moments=True)
+    sc_s, sh_s, m_s, r_s = ops.gn_stats(outs[0], o1, gamma, beta, 32, want_moments=True)
+    xc = torch.cat([nchw(o) for o in outs], 1).double().reshape(B, 32, -1)
+    close(m_f.cpu(), xc.mean(-1), 1e-6, "fused mean")
+    close(r_f.cpu(), (xc.var(-1, unbiased=False) + 1e-5).rsqrt(), 2e-6, "fused rstd")
+    assert torch.allclose(sc_f, sc_s, rtol=1e-6, atol=1e-7) and torch.allclose(sh_f, sh_s, rtol=1e-5, atol=1e-6)
+
+
 def test_gn_no_silu_1x1(cdx_mod):
     """Attention's qkv projection: conv1x1(gn(x)), no activation."""
     ops = cdx_mod.ops
