@@ -25,7 +25,7 @@ class ConvArgs(C.Structure):
                 ("batch", _i), ("hin", _i), ("win", _i), ("hout", _i), ("wout", _i),
                 ("cout", _i), ("ksize", _i), ("stride", _i), ("flags", _i),
                 ("wpacked", _f), ("bias", _f), ("gn_scale", _f), ("gn_shift", _f),
-                ("temb", _f), ("temb_ld", _i), ("residual", _f), ("out", _f), ("out_ld", _i), ("stats_out", _f)]
+                ("temb", _f), ("temb_ld", _i), ("residual", _f), ("out", _f), ("out_ld", _i), ("wpacked_wino", _f), ("stats_out", _f)]
 
 
 class GnStatsArgs(C.Structure):
@@ -93,11 +93,11 @@ OPS = {
 }
 
 # every exported symbol include/cdx.h declares (checked by tests/test_abi.py without a GPU)
-TILE_NAMES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "64x128", 4: "64x64", 5: "S32x32", 6: "S64x32"}
+TILE_NAMES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "64x128", 4: "64x64", 5: "S32x32", 6: "S64x32", 7: "wino128x128"}
 
 EXPORTS = (["cdx_abi_version", "cdx_strerror", "cdx_launch_count",
             "cdx_conv_packed_floats", "cdx_conv_pack_weights_f32", "cdx_conv_select_tile", "cdx_conv_f32_tile",
-            "cdx_conv_stats_slots"]
+            "cdx_conv_stats_slots", "cdx_conv_wino_packed_floats", "cdx_conv_pack_weights_wino_f32"]
            + [f"cdx_{op}" for op in OPS] + [f"cdx_{op}_workspace" for op in OPS])
 
 _lib = None
@@ -126,6 +126,10 @@ def lib() -> C.CDLL:
     L.cdx_conv_packed_floats.argtypes = [_i, _i, _i, _i]
     L.cdx_conv_pack_weights_f32.restype = C.c_int
     L.cdx_conv_pack_weights_f32.argtypes = [_f, _i, _i, _i, _i, _f]
+    L.cdx_conv_wino_packed_floats.restype = C.c_size_t
+    L.cdx_conv_wino_packed_floats.argtypes = [_i, _i, _i]
+    L.cdx_conv_pack_weights_wino_f32.restype = C.c_int
+    L.cdx_conv_pack_weights_wino_f32.argtypes = [_f, _i, _i, _i, _f]
     L.cdx_conv_select_tile.restype = C.c_int
     L.cdx_conv_select_tile.argtypes = [C.POINTER(ConvArgs)]
     L.cdx_conv_stats_slots.restype = C.c_int32
@@ -171,4 +175,16 @@ def pack_conv_weights(w_oihw, c0: int, c1: int):
         raise CdxError("cdx_conv_packed_floats: bad arguments")
     out = np.empty(n, np.float32)
     check(lib().cdx_conv_pack_weights_f32(w.ctypes.data, c0, c1, cout, k, out.ctypes.data), "cdx_conv_pack_weights_f32")
+    return out
+
+
+def pack_conv_weights_wino(w_oihw, c0: int, c1: int):
+    """numpy OIHW 3x3 float32 -> Winograd-transformed, fragment-ordered float32 image (host)."""
+    import numpy as np
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    cout, cin, k, _ = w.shape
+    assert k == 3 and cin == c0 + c1
+    n = int(lib().cdx_conv_wino_packed_floats(c0, c1, cout))
+    out = np.empty(n, np.float32)
+    check(lib().cdx_conv_pack_weights_wino_f32(w.ctypes.data, c0, c1, cout, out.ctypes.data), "cdx_conv_pack_weights_wino_f32")
     return out

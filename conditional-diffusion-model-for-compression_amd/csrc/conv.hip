@@ -2,7 +2,7 @@
 // (U3/U4/U5/U8/U9 of SURVEY.md section 8a; no reference file exists to cite.)
 #include <string.h>
 
-#include "conv_kernel.h"
+#include "conv_wino.h"
 
 extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, size_t, cdx_stream_t stream);
 
@@ -46,6 +46,42 @@ extern "C" int cdx_conv_pack_weights_f32(const float* w, int32_t c0, int32_t c1,
     return CDX_OK;
 }
 
+extern "C" size_t cdx_conv_wino_packed_floats(int32_t c0, int32_t c1, int32_t cout) {
+    if (c0 <= 0 || c1 < 0 || cout <= 0) return 0;
+    const size_t ntiles = (cout + 31) / 32, nch = chunks_of(c0) + chunks_of(c1);
+    return ntiles * nch * 16384 + 4096;
+}
+
+extern "C" int cdx_conv_pack_weights_wino_f32(const float* w, int32_t c0, int32_t c1, int32_t cout, float* packed) {
+    CDX_REQUIRE(w && packed && c0 > 0 && c1 >= 0 && cout > 0);
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int ctot = c0 + c1;
+    const int nch0 = chunks_of(c0), nch = nch0 + chunks_of(c1), ntiles = (cout + 31) / 32;
+    float* o = packed;
+    for (int nt = 0; nt < ntiles; ++nt)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int s = 0; s < 4; ++s)
+                for (int e = 0; e < 4; ++e)
+                    for (int xq = 0; xq < 4; ++xq)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j) {
+                                const int n = nt * 32 + (lane & 31);
+                                const int cl = (ch < nch0 ? ch : ch - nch0) * CDX_CONV_KC + 8 * s + 4 * (lane >> 5) + e;
+                                const int csrc = ch < nch0 ? c0 : c1;
+                                double u = 0.0;
+                                if (n < cout && cl < csrc) {
+                                    const int c = (ch < nch0 ? 0 : c0) + cl;
+                                    const float* g = w + ((size_t)n * ctot + c) * 9;
+                                    const int xi = 4 * xq + j, i = xi >> 2, jj = xi & 3;
+                                    for (int a = 0; a < 3; ++a)
+                                        for (int b = 0; b < 3; ++b) u += G[i][a] * (double)g[a * 3 + b] * G[jj][b];
+                                }
+                                *o++ = (float)u;
+                            }
+    memset(o, 0, 4096 * sizeof(float));
+    return CDX_OK;
+}
+
 namespace {
 
 struct Tile { int wcfg, bm, bn, wm; };
@@ -61,8 +97,14 @@ Tile tile_of(int wcfg) {
         case WCFG_2x2x1: return {wcfg, 64, 64, 2};
         case WCFG_S32: return {wcfg, 32, 32, 1};
         case WCFG_S64: return {wcfg, 64, 32, 1};
+        case WCFG_WINO: return {wcfg, 128, 128, 1};
         default: return {-1, 0, 0, 0};
     }
+}
+
+// Winograd F(2x2,3x3) applies to 3x3 stride-1 layers whose rows hold at least one 32-pixel tile row.
+bool wino_ok(const cdx_conv_args* a) {
+    return a->ksize == 3 && a->stride == 1 && a->wout >= 32 && a->wpacked_wino != nullptr && aligned16(a->wpacked_wino);
 }
 
 // Tile-shape heuristic.  Depends on the LAYER shape only, never on the batch: a different tile changes the
@@ -76,6 +118,7 @@ Tile select_tile(const cdx_conv_args* a) {
     if (a->ksize == 3) {
         const int hw = a->hout * a->wout;
         if (hw <= kSplitKMaxPixels) t = tile_of(a->stride == 1 && hw >= 256 ? WCFG_S64 : WCFG_S32);
+        else if (wino_ok(a) && a->cout >= 96) t = tile_of(WCFG_WINO);
     }
     return t;
 }
@@ -83,6 +126,7 @@ Tile select_tile(const cdx_conv_args* a) {
 bool tile_allowed(const cdx_conv_args* a, int wcfg) {
     if (a->ksize == 1) return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1;
     if (a->stride == 2) return wcfg == WCFG_1x4x2 || wcfg == WCFG_2x2x1 || wcfg == WCFG_S32;
+    if (wcfg == WCFG_WINO) return wino_ok(a);
     return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1 || wcfg == WCFG_S32 || wcfg == WCFG_S64;
 }
 
@@ -159,6 +203,11 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
 
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (t.wcfg == WCFG_WINO || (experimental && tile >= 32)) {
+        if (!wino_ok(a)) return CDX_ENOTSUP;
+        p.w = a->wpacked_wino;
+        return conv_dispatch_wino(experimental ? tile : 0, p, st);
+    }
     if (experimental) return conv_dispatch_exp(logtw, t.wcfg, p, st);
     if (a->ksize == 1) return conv_dispatch_k1s1(logtw, t.wcfg, p, st);
     if (a->stride == 1) return conv_dispatch_k3s1(logtw, t.wcfg, p, st);

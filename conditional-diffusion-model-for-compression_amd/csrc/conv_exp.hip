@@ -7,12 +7,12 @@ namespace cdx {
 int conv_dispatch_exp(int logtw, int wcfg, const ConvParams& p, hipStream_t stream) {
     if (logtw != 5) return CDX_ENOTSUP;
     switch (wcfg) {
-        EXP_CASE(16, 1, 0)
-        EXP_CASE(17, 4, 0)
-        EXP_CASE(18, 4, OPT_OCC2 | OPT_STAGGER)
-        EXP_CASE(19, 4, OPT_OCC2 | OPT_SPLIT_LDS_READS)
-        EXP_CASE(20, 3, OPT_OCC2)
-        EXP_CASE(21, 6, OPT_OCC2)
+        EXP_CASE(16, 4, OPT_OCC2 | OPT_ABL_NO_STAGE)
+        EXP_CASE(17, 4, OPT_OCC2 | OPT_ABL_NO_EPILOGUE)
+        EXP_CASE(18, 4, OPT_OCC2 | OPT_ABL_NO_STAGE | OPT_ABL_NO_EPILOGUE)
+        EXP_CASE(19, 4, OPT_OCC2 | OPT_ABL_ONE_WG)
+        EXP_CASE(20, 4, OPT_OCC2 | OPT_ABL_ONE_WG | OPT_ABL_NO_STAGE | OPT_ABL_NO_EPILOGUE)
+        EXP_CASE(21, 4, 0)
         default: return CDX_ENOTSUP;
     }
 }

@@ -17,6 +17,8 @@
 // LDS image: pixel stride PS = 36 floats (32 + 4 pad), row stride RS = multiple of 64 floats, which
 // makes every ds_read_b128 lane group hit 16 distinct 4-bank slots (conflict-free) for TW >= 16.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace cdx {
@@ -49,7 +51,11 @@ struct ConvParams {
 enum { OPT_SPLIT_LDS_READS = 1,  // hide the 16-B alignment: 2 x ds_read2_b32 per fragment instead of ds_read_b128
        OPT_EXACT_SILU = 2,       // expf + IEEE divide instead of v_exp_f32 + v_rcp_f32
        OPT_OCC2 = 4,             // __launch_bounds__(256, 2): up to 256 VGPRs, 2 workgroups per CU
-       OPT_STAGGER = 8 };        // delay every second resident workgroup of the first round by ~half a tile
+       OPT_STAGGER = 8,          // delay every second resident workgroup of the first round by ~half a tile
+       // timing-only ablations (WRONG RESULTS; conv_exp.hip only):
+       OPT_ABL_NO_STAGE = 16,    // chunks after the first skip the global loads + LDS writes (barriers stay)
+       OPT_ABL_NO_EPILOGUE = 32, // no output stores / residual reads (one store keeps the accumulators live)
+       OPT_ABL_ONE_WG = 64 };    // declare 96 KiB of LDS: one workgroup per CU
 template <int KS_, int STRIDE_, int LOGTW_, int WM_, int WN_, int MT_, int WK_ = 1, int PF_ = 1, int OPT_ = 0>
 struct ConvCfg {
     static constexpr int KS = KS_, STRIDE = STRIDE_, LOGTW = LOGTW_, WM = WM_, WN = WN_, MT = MT_, WK = WK_, PF = PF_, OPT = OPT_;
@@ -84,7 +90,7 @@ __device__ __forceinline__ float silu_f(float v) {
 template <class C>
 __global__ __launch_bounds__(256, (C::OPT & OPT_OCC2) ? 2 : 3) void conv_kernel(const ConvParams p) {
     constexpr int KC = C::KC, PS = C::PS, RS = C::RS, TAPS = C::TAPS, MT = C::MT, NPASS = C::NPASS;
-    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[(C::OPT & OPT_ABL_ONE_WG) ? 24576 : C::LDS_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -201,9 +207,10 @@ __global__ __launch_bounds__(256, (C::OPT & OPT_OCC2) ? 2 : 3) void conv_kernel(
     };
     issue_loads(0);
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        write_lds();
+        if (!(C::OPT & OPT_ABL_NO_STAGE) || chunk == 0) write_lds();
         __syncthreads();
-        if (chunk + 1 < p.nchunks) issue_loads(chunk + 1);   // lands under this chunk's MFMAs
+        if (!(C::OPT & OPT_ABL_NO_STAGE))
+            if (chunk + 1 < p.nchunks) issue_loads(chunk + 1);   // lands under this chunk's MFMAs
         if (nvalid) {
             const float* __restrict__ wc = wp + (size_t)chunk * (TAPS * 1024);
             f32x4 an[MT];
@@ -260,6 +267,15 @@ __global__ __launch_bounds__(256, (C::OPT & OPT_OCC2) ? 2 : 3) void conv_kernel(
 
     // ---- epilogue: acc[t][r] is out[pixel (r&3) + 8*(r>>2) + 4*lh of tile t][channel li] ----
     if (!nvalid) return;
+    if constexpr (C::OPT & OPT_ABL_NO_EPILOGUE) {
+        float keep = 0.f;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) keep += acc[t][r];
+        if (keep == 123.456f) p.out[0] = keep;
+        return;
+    }
     const int n = ntile * 32 + li;
     const bool nok = n < p.Cout;
     float add = 0.f;
@@ -268,25 +284,44 @@ __global__ __launch_bounds__(256, (C::OPT & OPT_OCC2) ? 2 : 3) void conv_kernel(
         if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
     }
     double s1 = 0.0, s2 = 0.0;      // per-channel sum / sum of squares of the stored values (GroupNorm of `out`)
+    // The residual / stats tests are hoisted out of the unrolled loops on purpose: a per-element "load or not"
+    // makes hipcc branch around every load and wait vmcnt(0) each time (64 serial HBM round trips).
+    auto epilogue = [&](auto has_res, auto has_stats) __attribute__((always_inline)) {
+        float rv[MT][16];
+        if constexpr (decltype(has_res)::value) {
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
+            for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (wm * MT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int oy = oy0 + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
-            if (nok && oy < p.Hout && ox < p.Wout) {
-                const size_t pix = ((size_t)b * p.Hout + oy) * p.Wout + ox;
-                float v = acc[t][r] + add;
-                if (p.residual) v += p.residual[pix * p.Cout + n];
-                p.out[pix * p.out_ld + n] = v;
-                if (p.stats) {
-                    const double d = (double)v;
-                    s1 += d;
-                    s2 = fma(d, d, s2);
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (wm * MT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int oy = min(oy0 + (m >> C::LOGTW), p.Hout - 1), ox = min(ox0 + (m & (C::TW - 1)), p.Wout - 1);
+                    rv[t][r] = p.residual[(((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + (nok ? n : 0)];
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm * MT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int oy = oy0 + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
+                if (nok && oy < p.Hout && ox < p.Wout) {
+                    const size_t pix = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+                    float v = acc[t][r] + add;
+                    if constexpr (decltype(has_res)::value) v += rv[t][r];
+                    p.out[pix * p.out_ld + n] = v;
+                    if constexpr (decltype(has_stats)::value) {
+                        const double d = (double)v;
+                        s1 += d;
+                        s2 = fma(d, d, s2);
+                    }
                 }
             }
         }
-    }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (p.residual) { if (p.stats) epilogue(T_{}, T_{}); else epilogue(T_{}, F_{}); }
+    else { if (p.stats) epilogue(F_{}, T_{}); else epilogue(F_{}, F_{}); }
     if (p.stats) {      // wave-uniform
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
@@ -309,7 +344,8 @@ inline int conv_launch(const ConvParams& p, hipStream_t stream) {
 
 // tile-shape ids used by the dispatcher (WM x WN x MT [x WK]); the S* shapes split K over the 4 waves
 // and exist for the low-resolution levels, where the big tiles would leave most CUs idle.
-enum { WCFG_1x4x4 = 0, WCFG_2x2x2 = 1, WCFG_4x1x1 = 2, WCFG_1x4x2 = 3, WCFG_2x2x1 = 4, WCFG_S32 = 5, WCFG_S64 = 6 };
+enum { WCFG_1x4x4 = 0, WCFG_2x2x2 = 1, WCFG_4x1x1 = 2, WCFG_1x4x2 = 3, WCFG_2x2x1 = 4, WCFG_S32 = 5, WCFG_S64 = 6,
+       WCFG_WINO = 7 };
 
 int conv_dispatch_k3s1(int logtw, int wcfg, const ConvParams& p, hipStream_t stream);
 int conv_dispatch_k1s1(int logtw, int wcfg, const ConvParams& p, hipStream_t stream);

@@ -1,0 +1,314 @@
+// Winograd F(2x2, 3x3) convolution on the gfx950 fp32 matrix pipe: 16 transform-domain products per 2x2 output
+// tile instead of 36 direct ones -> 2.25x fewer v_mfma_f32_32x32x2_f32 for the same float32 result
+// (Lavin & Gray 2016;  Y = A^T [ (G g G^T) (.) (B^T d B) ] A,  B^T, G, A^T below).
+//
+// Mapping (why this fits CDNA4): the usual obstacles are 16 accumulator sets per output block and a 4x larger
+// transformed-input image.  Here one wave per SIMD owns the whole 512-entry register file:
+//   * a workgroup (4 waves) owns 4 x 32 output pixels = 32 Winograd tiles of one image x 128 output channels;
+//     the 4 waves split the channels (32 each), so every wave holds acc[16 xi][32 tiles x 32 ch] = 256 registers;
+//   * the input halo (6 x 34 pixels x 32 channels, GroupNorm/SiLU/upsample/concat applied while staging, exactly
+//     as in conv_kernel.h) sits in LDS ONCE; each lane (tile = lane & 31, channel half = lane >> 5) reads its
+//     4x4 patch and computes B^T d B IN REGISTERS (32 adds per channel) -- no transformed image in LDS;
+//   * weights U = G g G^T are transformed and packed on the host so that a lane's 16-B fragment carries four
+//     xi of one channel: [ntile][chunk][s][e][xiq][lane][4] (fragment-ordered, L2-resident, ring-prefetched);
+//   * the output transform A^T M A is in-register too (the 16 accumulators of a lane share (tile, channel));
+//   * LDS is double buffered: the next chunk is written while this chunk's MFMAs run, one barrier per chunk.
+// Numerics: float32 throughout; transform constants are exact (0, +-1, +-1/2) so the only extra error over the
+// direct kernel is the reassociation of the sum (measured in tests against float64).
+#pragma once
+#include "conv_kernel.h"
+
+namespace cdx {
+
+template <int PF_, int OPT_>
+struct WinoCfg {
+    static constexpr int PF = PF_, OPT = OPT_;
+    static constexpr int KC = CDX_CONV_KC, PS = KC + 4;
+    static constexpr int TW = 32, TH = 4, LOGTW = 5;             // output pixels per workgroup: 4 rows x 32 cols
+    static constexpr int HH = TH + 2, HW = TW + 2;
+    static constexpr int RS = ((HW * PS + 63) / 64) * 64;
+    static constexpr int BUF_FLOATS = HH * RS;
+    static constexpr int NPIX = HH * HW;
+    static constexpr int NPASS = (NPIX + 31) / 32;
+    static constexpr int GPC = 16;                                // (s, e) groups per chunk, 16 MFMAs each
+    static constexpr int BM = 128, BN = 128;
+    static_assert(64 % (4 * PF) == 0, "ring depth (4*PF fragments) must divide the 64 fragments per chunk");
+};
+
+template <class C>
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p) {
+    constexpr int KC = C::KC, PS = C::PS, RS = C::RS, NPASS = C::NPASS, GPC = C::GPC, PF = C::PF;
+    __shared__ __attribute__((aligned(16))) float lds[2 * C::BUF_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int b = bx / p.tiles_y;
+    const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+
+    // ---- halo loader (same scheme as conv_kernel.h): thread -> (pixel slot pl, channel quad q) ----
+    const int q = tid & 7, pl = tid >> 3;
+    int soff[NPASS];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int hp = i * 32 + pl;
+        const int hy = hp / C::HW, hx = hp - hy * C::HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool ok = hp < C::NPIX && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+        soff[i] = ok ? ((b * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups)) : 0;
+        vmask |= ok ? (1u << i) : 0u;
+    }
+    f32x4 pre[NPASS];
+    f32x4 gsc, gsh;
+    bool cvalid;
+
+    auto issue_loads = [&](int chunk) {
+        const int s = chunk >= p.nchunk0;
+        const int cl = (s ? chunk - p.nchunk0 : chunk) * KC + q * 4;
+        const int cs = p.csrc[s];
+        cvalid = cl < cs;
+        const float* __restrict__ base = p.src[s] + (cvalid ? cl : 0);
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) pre[i] = *reinterpret_cast<const f32x4*>(base + (size_t)soff[i] * cs);
+        if (p.gn) {
+            const int cg = cvalid ? (s ? p.csrc[0] : 0) + cl : 0;
+            gsc = *reinterpret_cast<const f32x4*>(p.gscale + (size_t)b * p.ctot + cg);
+            gsh = *reinterpret_cast<const f32x4*>(p.gshift + (size_t)b * p.ctot + cg);
+        }
+    };
+    auto write_lds = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int hp = i * 32 + pl;
+            const int hy = hp / C::HW, hx = hp - hy * C::HW;
+            f32x4 v = pre[i];
+            const bool ok = cvalid && ((vmask >> i) & 1u);
+            if (p.gn) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], gsc[e], gsh[e]);
+            }
+            if (p.silu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f<false>(v[e]);
+            }
+            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (hp < C::NPIX) *reinterpret_cast<f32x4*>(&buf[hy * RS + hx * PS + q * 4]) = v;
+        }
+    };
+
+    // ---- operand addressing: lane = (Winograd tile li, channel half lh) ----
+    const int li = lane & 31, lh = lane >> 5;
+    const int wty = li >> 4, wtx = li & 15;                            // tile (row, col) inside the 2 x 16 tile grid
+    const int a_base = (2 * wty) * RS + (2 * wtx) * PS + lh * 4;        // top-left pixel of the 4x4 input patch
+    const int ntile = blockIdx.y * 4 + wn;
+    const bool nvalid = ntile * 32 < p.Cout;
+    // packed weights: [ntile][chunk][s][e][xiq][lane][4]: group g = s*4+e is 4 KiB (four 1-KiB fragments)
+    const float* __restrict__ wp = p.w + ((size_t)(nvalid ? ntile : 0) * p.nchunks) * 16384 + lane * 4;
+
+    // Accumulators.  bias + temb + residual are injected HERE rather than added in the epilogue: with
+    // Y = A^T M A, setting M[0][0] = R00, M[0][3] = -R01, M[3][0] = -R10, M[3][3] = R11 adds exactly R to the 2x2
+    // output.  The 64 residual loads thus overlap the first halo fetch and cost no registers of their own.
+    const int n = ntile * 32 + li;
+    const bool nok = nvalid && n < p.Cout;
+    f32x16 acc[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    if (nok) {
+        float add = p.bias ? p.bias[n] : 0.f;
+        if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
+        // NOTE: the residual test is hoisted out of the unrolled loops on purpose -- a per-element "load or not"
+        // makes hipcc branch around every load and wait vmcnt(0) each time (64 serial HBM round trips).
+        if (p.residual) {
+            float rv[64];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int oy = oy0 + 2 * (tile >> 4), ox = ox0 + 2 * (tile & 15);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int y = min(oy + (k >> 1), p.Hout - 1), x = min(ox + (k & 1), p.Wout - 1);   // clamped: masked at store
+                    rv[r * 4 + k] = p.residual[(((size_t)b * p.Hout + y) * p.Wout + x) * p.Cout + n];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[0][r] = rv[r * 4 + 0] + add;
+                acc[3][r] = -(rv[r * 4 + 1] + add);
+                acc[12][r] = -(rv[r * 4 + 2] + add);
+                acc[15][r] = rv[r * 4 + 3] + add;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[0][r] = add;
+                acc[3][r] = -add;
+                acc[12][r] = -add;
+                acc[15][r] = add;
+            }
+        }
+    }
+
+    // Weight fragments: 1 KiB each (64 lanes x 16 B), consumed in order f = g*4 + xiq; a ring of RF fragments
+    // (RF*4 MFMAs = RF*256 cycles of cover) is kept in flight and wraps into the next chunk / the tail pad.
+    constexpr int RF = 4 * PF;
+    f32x4 ring[RF];
+#pragma unroll
+    for (int f = 0; f < RF; ++f) ring[f] = *reinterpret_cast<const f32x4*>(wp + f * 256);
+
+    auto read_patch = [&](const float* buf, int s, f32x4 (&d)[16]) {
+        int ab = a_base;
+        asm volatile("" : "+v"(ab));              // opaque: no reuse of fragments across s (register pressure)
+        __builtin_assume((ab & 3) == 0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+                d[a * 4 + bb] = *reinterpret_cast<const f32x4*>(&buf[ab + a * RS + bb * PS + s * 8]);
+    };
+
+    // ---- pipeline prologue: chunk 0 in buffer 0, chunk 1 in flight ----
+    issue_loads(0);
+    write_lds(lds);
+    if (p.nchunks > 1) issue_loads(1);
+    __syncthreads();
+
+    if (!nvalid) {
+        // A wave whose 32 output channels lie beyond cout only helps with the staging and the barriers.
+        for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+            if (chunk + 1 < p.nchunks) {
+                write_lds(lds + ((chunk + 1) & 1) * C::BUF_FLOATS);
+                if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    auto chunk_body = [&](const int chunk, const bool more) __attribute__((always_inline)) {
+        const float* cur = lds + (chunk & 1) * C::BUF_FLOATS;
+        float* nxt = lds + ((chunk + 1) & 1) * C::BUF_FLOATS;
+        const float* __restrict__ wc = wp + (size_t)chunk * 16384;
+        f32x4 d[16];
+#pragma unroll
+        for (int g = 0; g < GPC; ++g) {
+            const int s = g >> 2, e = g & 3;
+            if (e == 0 && (!(C::OPT & 2) || g == 0)) read_patch(cur, s, d);   // OPT 2 (ablation): one patch read per chunk
+            // halfway through the chunk: stage the next chunk into the other buffer, start the one after
+            if (g == GPC / 2 && more && !(C::OPT & 4)) {   // OPT 4 (ablation): no staging of later chunks
+                write_lds(nxt);
+                if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // row pass of B^T d B for channel e: r[i][b]
+            float r[4][4];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const float t0 = d[0 + bb][e], t1 = d[4 + bb][e], t2 = d[8 + bb][e], t3 = d[12 + bb][e];
+                r[0][bb] = t0 - t2;
+                r[1][bb] = t1 + t2;
+                r[2][bb] = t2 - t1;
+                r[3][bb] = t1 - t3;
+            }
+#pragma unroll
+            for (int xq = 0; xq < 4; ++xq) {      // xi = 4*xq + j: row xq of V, column j
+                const int f = g * 4 + xq;
+                const f32x4 bq = ring[f % RF];
+                if constexpr (!(C::OPT & 1))   // OPT 1 (timing ablation): never refill the weight ring
+                    ring[f % RF] = *reinterpret_cast<const f32x4*>(wc + (f + RF) * 256);
+                float v0 = r[xq][0] - r[xq][2], v1 = r[xq][1] + r[xq][2];
+                float v2 = r[xq][2] - r[xq][1], v3 = r[xq][1] - r[xq][3];
+                if constexpr (C::OPT & 8) {   // OPT 8 (timing ablation): no input transform, raw patch values
+                    v0 = d[xq * 4 + 0][e]; v1 = d[xq * 4 + 1][e]; v2 = d[xq * 4 + 2][e]; v3 = d[xq * 4 + 3][e];
+                }
+                acc[xq * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, bq[0], acc[xq * 4 + 0], 0, 0, 0);
+                acc[xq * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, bq[1], acc[xq * 4 + 1], 0, 0, 0);
+                acc[xq * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2, bq[2], acc[xq * 4 + 2], 0, 0, 0);
+                acc[xq * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(v3, bq[3], acc[xq * 4 + 3], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep each group's loads / VALU / MFMAs where they are written
+        }
+    };
+
+    for (int chunk = 0; chunk + 1 < p.nchunks; ++chunk) {
+        chunk_body(chunk, true);
+        __syncthreads();
+    }
+    chunk_body(p.nchunks - 1, false);
+
+    // ---- output transform A^T M A (in registers) + epilogue ----
+    if constexpr (C::OPT & 16) {   // OPT 16 (timing ablation): no output transform / residual / stores
+        float keep = 0.f;
+#pragma unroll
+        for (int x = 0; x < 16; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) keep += acc[x][r];
+        if (keep == 123.456f) p.out[0] = keep;
+        return;
+    }
+    // Opaque copies of the tile origin / lane half: otherwise hipcc hoists all 64 output-address computations
+    // above the main loop and spills them (and accumulators) to scratch.
+    int eoy0 = oy0, eox0 = ox0, elh = lh;
+    asm volatile("" : "+s"(eoy0), "+s"(eox0), "+v"(elh));
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        // this register's tile: MFMA row (r&3) + 8*(r>>2) + 4*lh  ->  (tile row, tile col)
+        const int tile = (r & 3) + 8 * (r >> 2) + 4 * elh;
+        const int oy = eoy0 + 2 * (tile >> 4), ox = eox0 + 2 * (tile & 15);
+        float t[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
+            t[1][j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float y[2] = {t[a][0] + t[a][1] + t[a][2], t[a][1] - t[a][2] - t[a][3]};
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                if (nok && oy + a < p.Hout && ox + bb < p.Wout) {
+                    const size_t pix = ((size_t)b * p.Hout + oy + a) * p.Wout + ox + bb;
+                    const float v = y[bb];
+                    p.out[pix * p.out_ld + n] = v;
+                    if (p.stats) {
+                        const double dv = (double)v;
+                        s1 += dv;
+                        s2 = fma(dv, dv, s2);
+                    }
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lh == 0 && nok) {
+            const int slot = ty * p.tiles_x + tx;
+            const int nslots = p.tiles_y * p.tiles_x;
+            double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + n) * 2;
+            o[0] = s1;
+            o[1] = s2;
+        }
+    }
+}
+
+template <class C>
+inline int conv_wino_launch(const ConvParams& p, hipStream_t stream) {
+    dim3 grid(p.tiles_x * p.tiles_y * p.B, ceil_div(p.Cout, C::BN));
+    hipLaunchKernelGGL(conv_wino_kernel<C>, grid, dim3(256), 0, stream, p);
+    return check_launch();
+}
+
+int conv_dispatch_wino(int variant, const ConvParams& p, hipStream_t stream);
+
+}  // namespace cdx

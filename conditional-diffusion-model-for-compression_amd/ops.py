@@ -33,13 +33,17 @@ def _ws(nbytes: int, device):
 class PackedConv:
     """Device-resident packed weights of one convolution (built once per layer)."""
 
-    def __init__(self, w_oihw, bias, c0: int, c1: int = 0, device="cuda"):
+    def __init__(self, w_oihw, bias, c0: int, c1: int = 0, device="cuda", winograd: bool = True):
         import numpy as np
         w = np.asarray(w_oihw, dtype=np.float32)
         self.cout, cin, self.ksize, _ = w.shape
         assert cin == c0 + c1, (cin, c0, c1)
         self.c0, self.c1 = c0, c1
         self.w = torch.from_numpy(_abi.pack_conv_weights(w, c0, c1)).to(device)
+        # 3x3 layers also carry the Winograd-domain image; the library decides per launch which one to use
+        self.w_wino = None
+        if winograd and self.ksize == 3:
+            self.w_wino = torch.from_numpy(_abi.pack_conv_weights_wino(w, c0, c1)).to(device)
         self.bias = None if bias is None else torch.as_tensor(np.asarray(bias, np.float32)).to(device)
 
 
@@ -58,6 +62,7 @@ def conv_args(pc: PackedConv, src0, src1, out, *, stride=1, upsample=False, gn=N
     a.batch, a.hin, a.win, a.hout, a.wout = B, hin, win, hout, wout
     a.cout, a.ksize, a.stride, a.flags = pc.cout, pc.ksize, stride, flags
     a.wpacked, a.bias = _ptr(pc.w), _ptr(pc.bias)
+    a.wpacked_wino = _ptr(pc.w_wino)
     if gn is not None:
         a.gn_scale, a.gn_shift = _ptr(gn[0]), _ptr(gn[1])
     if temb is not None:

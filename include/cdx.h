@@ -76,6 +76,9 @@ typedef struct cdx_conv_args {
     const float* residual; /* [batch, hout, wout, cout] or NULL: out += residual */
     float* out;            /* [batch, hout, wout, out_ld], channels [0, cout) written */
     int32_t out_ld;
+    const float* wpacked_wino; /* NULL, or the cdx_conv_pack_weights_wino_f32 image of the same weights: lets the library
+                              run 3x3 stride-1 layers (wout >= 32, cout >= 96) as Winograd F(2x2,3x3) -- same float32
+                              result up to summation order, 2.25x fewer MFMAs */
     double* stats_out;     /* NULL, or [batch, cdx_conv_stats_slots(a), cout, 2]: per-slot (sum, sum of squares) of the
                               values stored to `out`, float64, for cdx_gn_finalize_f32 (GroupNorm of `out` without
                               re-reading it) */
@@ -97,7 +100,8 @@ enum {
     CDX_TILE_64x128 = 3,  /* stride 2: 1x4, 2 M-tiles               */
     CDX_TILE_64x64 = 4,   /* stride 2: 2x2, 1 M-tile                */
     CDX_TILE_S32x32 = 5,  /* low-resolution levels: 4 waves split K */
-    CDX_TILE_S64x32 = 6
+    CDX_TILE_S64x32 = 6,
+    CDX_TILE_WINO = 7     /* Winograd F(2x2,3x3), 128 pixels x 128 channels, needs wpacked_wino */
 };
 int cdx_conv_select_tile(const cdx_conv_args* a);
 int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
@@ -111,6 +115,11 @@ int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void* workspace, siz
 size_t cdx_conv_packed_floats(int32_t c0, int32_t c1, int32_t cout, int32_t ksize);
 int cdx_conv_pack_weights_f32(const float* w_oihw, int32_t c0, int32_t c1, int32_t cout,
                               int32_t ksize, float* packed);
+/* HOST: Winograd image of a 3x3 weight: U = G g G^T (float64, rounded once), fragment-ordered
+ *   [ntile][chunk][s = 0..3][e = 0..3][xiq = 0..3][lane = 0..63][j = 0..3]
+ *   = U[xi = 4*xiq + j][n = 32*ntile + (lane&31)][c = chunk_base + 8*s + 4*(lane>>5) + e],  + 16 KiB zero pad. */
+size_t cdx_conv_wino_packed_floats(int32_t c0, int32_t c1, int32_t cout);
+int cdx_conv_pack_weights_wino_f32(const float* w_oihw, int32_t c0, int32_t c1, int32_t cout, float* packed);
 
 /* ------------------------------------------------------------------------------------------
  * U2: GroupNorm statistics of cat[src0, src1] -> per-(batch, channel) scale / shift
