@@ -32,6 +32,7 @@ struct WinoCfg {
     static constexpr int NPASS = (NPIX + 31) / 32;
     static constexpr int GPC = 16;                                // (s, e) groups per chunk, 16 MFMAs each
     static constexpr int BM = 128, BN = 128;
+    static_assert(NPASS + 1 <= GPC, "staging passes must fit in the chunk's groups");
     static_assert(64 % (4 * PF) == 0, "ring depth (4*PF fragments) must divide the 64 fragments per chunk");
 };
 
@@ -84,24 +85,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p) {
             gsh = *reinterpret_cast<const f32x4*>(p.gshift + (size_t)b * p.ctot + cg);
         }
     };
+    auto write_pass = [&](float* buf, int i) {      // transform + store halo pass i of the pending chunk
+        const int hp = i * 32 + pl;
+        const int hy = hp / C::HW, hx = hp - hy * C::HW;
+        f32x4 v = pre[i];
+        const bool ok = cvalid && ((vmask >> i) & 1u);
+        if (p.gn) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], gsc[e], gsh[e]);
+        }
+        if (p.silu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f<false>(v[e]);
+        }
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (hp < C::NPIX) *reinterpret_cast<f32x4*>(&buf[hy * RS + hx * PS + q * 4]) = v;
+    };
     auto write_lds = [&](float* buf) {
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            const int hp = i * 32 + pl;
-            const int hy = hp / C::HW, hx = hp - hy * C::HW;
-            f32x4 v = pre[i];
-            const bool ok = cvalid && ((vmask >> i) & 1u);
-            if (p.gn) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], gsc[e], gsh[e]);
-            }
-            if (p.silu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = silu_f<false>(v[e]);
-            }
-            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (hp < C::NPIX) *reinterpret_cast<f32x4*>(&buf[hy * RS + hx * PS + q * 4]) = v;
-        }
+        for (int i = 0; i < NPASS; ++i) write_pass(buf, i);
     };
 
     // ---- operand addressing: lane = (Winograd tile li, channel half lh) ----
@@ -111,7 +113,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p) {
     const int ntile = blockIdx.y * 4 + wn;
     const bool nvalid = ntile * 32 < p.Cout;
     // packed weights: [ntile][chunk][s][e][xiq][lane][4]: group g = s*4+e is 4 KiB (four 1-KiB fragments)
-    const float* __restrict__ wp = p.w + ((size_t)(nvalid ? ntile : 0) * p.nchunks) * 16384 + lane * 4;
+    // (scalar base + 32-bit lane offset: the fragment loads need no per-load 64-bit VALU address arithmetic)
+    const float* __restrict__ wp = p.w + ((size_t)(nvalid ? ntile : 0) * p.nchunks) * 16384;
+    const unsigned lane4 = lane * 4;
 
     // Accumulators.  bias + temb + residual are injected HERE rather than added in the epilogue: with
     // Y = A^T M A, setting M[0][0] = R00, M[0][3] = -R01, M[3][0] = -R10, M[3][3] = R11 adds exactly R to the 2x2
@@ -163,18 +167,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p) {
     constexpr int RF = 4 * PF;
     f32x4 ring[RF];
 #pragma unroll
-    for (int f = 0; f < RF; ++f) ring[f] = *reinterpret_cast<const f32x4*>(wp + f * 256);
-
-    auto read_patch = [&](const float* buf, int s, f32x4 (&d)[16]) {
-        int ab = a_base;
-        asm volatile("" : "+v"(ab));              // opaque: no reuse of fragments across s (register pressure)
-        __builtin_assume((ab & 3) == 0);
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb)
-                d[a * 4 + bb] = *reinterpret_cast<const f32x4*>(&buf[ab + a * RS + bb * PS + s * 8]);
-    };
+    for (int f = 0; f < RF; ++f) ring[f] = *reinterpret_cast<const f32x4*>(wp + f * 256 + lane4);
 
     // ---- pipeline prologue: chunk 0 in buffer 0, chunk 1 in flight ----
     issue_loads(0);
@@ -194,46 +187,82 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p) {
         return;
     }
 
+    // One chunk = 16 groups g = (s, e) of 16 MFMAs.  Software pipeline inside the chunk:
+    //   * the lane's 4x4 input patch is read in HALVES of two channels (16 x ds_read_b64 = channels e0, e0+1 of one
+    //     8-channel group): half h+1 is issued at the start of half h, a full 32 MFMAs (2048 cycles) before use;
+    //   * the transformed values of group g+1 are computed into the OTHER register set while group g's MFMAs
+    //     run -- distinct registers, so no VALU write waits for an in-flight MFMA to read its operand.
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    auto load_half = [&](const float* buf, int hh, f32x2 (&dst)[16]) {
+        int ab = a_base;
+        asm volatile("" : "+v"(ab));              // opaque: no CSE of LDS reads across halves
+        __builtin_assume((ab & 1) == 0);
+        const int coff = (hh >> 1) * 8 + (hh & 1) * 2;       // channel offset inside the chunk (+ 4*lh in a_base)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+                dst[a * 4 + bb] = *reinterpret_cast<const f32x2*>(&buf[ab + a * RS + bb * PS + coff]);
+    };
+    auto transform = [&](const f32x2 (&d)[16], int c, float (&v)[16]) {   // B^T d B for channel c of the half
+        float r[4][4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const float t0 = d[0 + bb][c], t1 = d[4 + bb][c], t2 = d[8 + bb][c], t3 = d[12 + bb][c];
+            r[0][bb] = t0 - t2;
+            r[1][bb] = t1 + t2;
+            r[2][bb] = t2 - t1;
+            r[3][bb] = t1 - t3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i * 4 + 0] = r[i][0] - r[i][2];
+            v[i * 4 + 1] = r[i][1] + r[i][2];
+            v[i * 4 + 2] = r[i][2] - r[i][1];
+            v[i * 4 + 3] = r[i][1] - r[i][3];
+        }
+    };
+
     auto chunk_body = [&](const int chunk, const bool more) __attribute__((always_inline)) {
         const float* cur = lds + (chunk & 1) * C::BUF_FLOATS;
         float* nxt = lds + ((chunk + 1) & 1) * C::BUF_FLOATS;
         const float* __restrict__ wc = wp + (size_t)chunk * 16384;
-        f32x4 d[16];
+        f32x2 dh[2][16];
+        float vv[2][16];
+        load_half(cur, 0, dh[0]);
+        transform(dh[0], 0, vv[0]);
 #pragma unroll
         for (int g = 0; g < GPC; ++g) {
-            const int s = g >> 2, e = g & 3;
-            if (e == 0 && (!(C::OPT & 2) || g == 0)) read_patch(cur, s, d);   // OPT 2 (ablation): one patch read per chunk
-            // halfway through the chunk: stage the next chunk into the other buffer, start the one after
-            if (g == GPC / 2 && more && !(C::OPT & 4)) {   // OPT 4 (ablation): no staging of later chunks
-                write_lds(nxt);
-                if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // row pass of B^T d B for channel e: r[i][b]
-            float r[4][4];
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                const float t0 = d[0 + bb][e], t1 = d[4 + bb][e], t2 = d[8 + bb][e], t3 = d[12 + bb][e];
-                r[0][bb] = t0 - t2;
-                r[1][bb] = t1 + t2;
-                r[2][bb] = t2 - t1;
-                r[3][bb] = t1 - t3;
+            const int hh = g >> 1;
+            if ((g & 1) == 0 && hh + 1 < 8) load_half(cur, hh + 1, dh[(hh + 1) & 1]);      // prefetch the next half
+            if (g + 1 < GPC) transform(dh[((g + 1) >> 1) & 1], (g + 1) & 1, vv[(g + 1) & 1]);   // next group's operands
+            // Second half of the chunk: stage the NEXT chunk into the other buffer, one halo pass per MFMA group
+            // (its ~30 VALU + one ds_write_b128 hide under the group's 16 MFMAs), then start the loads of the
+            // chunk after that.
+            if (more) {
+                constexpr int G0 = GPC - NPASS - 1;          // first staging group
+                if (g >= G0 && g < G0 + NPASS) write_pass(nxt, g - G0);
+                if (g == G0 + NPASS && chunk + 2 < p.nchunks) issue_loads(chunk + 2);
             }
 #pragma unroll
             for (int xq = 0; xq < 4; ++xq) {      // xi = 4*xq + j: row xq of V, column j
                 const int f = g * 4 + xq;
                 const f32x4 bq = ring[f % RF];
-                if constexpr (!(C::OPT & 1))   // OPT 1 (timing ablation): never refill the weight ring
-                    ring[f % RF] = *reinterpret_cast<const f32x4*>(wc + (f + RF) * 256);
-                float v0 = r[xq][0] - r[xq][2], v1 = r[xq][1] + r[xq][2];
-                float v2 = r[xq][2] - r[xq][1], v3 = r[xq][1] - r[xq][3];
-                if constexpr (C::OPT & 8) {   // OPT 8 (timing ablation): no input transform, raw patch values
-                    v0 = d[xq * 4 + 0][e]; v1 = d[xq * 4 + 1][e]; v2 = d[xq * 4 + 2][e]; v3 = d[xq * 4 + 3][e];
+                ring[f % RF] = *reinterpret_cast<const f32x4*>(wc + (f + RF) * 256 + lane4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[xq * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[g & 1][xq * 4 + j], bq[j], acc[xq * 4 + j], 0, 0, 0);
+            }
+            if constexpr (C::OPT & 64) {
+                // pin an even interleave inside the group: MFMA, 3 VALU, (1 LDS read), every 4th: 1 global load
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if ((i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if ((i & 7) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 }
-                acc[xq * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, bq[0], acc[xq * 4 + 0], 0, 0, 0);
-                acc[xq * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, bq[1], acc[xq * 4 + 1], 0, 0, 0);
-                acc[xq * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2, bq[2], acc[xq * 4 + 2], 0, 0, 0);
-                acc[xq * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(v3, bq[3], acc[xq * 4 + 3], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);   // keep each group's loads / VALU / MFMAs where they are written
         }

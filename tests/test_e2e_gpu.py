@@ -47,6 +47,8 @@ def test_native_library_is_the_path(cdx_mod):
     ("tiny", TINY),
     ("cfg1", dict(image_size=32, base_channels=64, channel_mult=(1, 2, 2, 2), attn_resolutions=(16,))),
     ("mid3", dict(image_size=64, base_channels=32, channel_mult=(1, 2, 4), attn_resolutions=(16,), head_dim=64)),
+    # >= 96 channels at >= 32 pixels wide: the 3x3 layers of levels 0 and 1 run as Winograd F(2x2,3x3)
+    ("wide_winograd", dict(image_size=64, base_channels=128, channel_mult=(1, 2, 2), attn_resolutions=(16,), num_res_blocks=1)),
 ])
 def test_unet_forward_matches_oracle(cdx_mod, record, name, over):
     import oracle
@@ -117,6 +119,26 @@ def test_fused_and_standalone_groupnorm_paths_agree(cdx_mod):
     a = cdx_mod.UNet(cfg, params, fuse_gn_stats=True).forward(x, t, cond)
     b = cdx_mod.UNet(cfg, params, fuse_gn_stats=False).forward(x, t, cond)
     assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())
+
+
+def test_sampler_winograd_path_vs_live_oracle(cdx_mod, record):
+    """A net wide enough that most 3x3 layers take the Winograd kernels (checked), 10 DDIM steps, against the oracle
+    run on this box's CPU: both PSNR gates."""
+    import ctypes
+    import oracle
+    cfg = cdx_mod.unet_config(image_size=64, base_channels=128, channel_mult=(1, 2), attn_resolutions=(32,), num_res_blocks=1)
+    params = cdx_mod.init_params(cfg, seed=12)
+    sb = cdx_mod.synthetic_batch(cfg, 12, 0, 2)
+    cond, tgt = torch.from_numpy(sb["cond"]), torch.from_numpy(sb["target"])
+    net = cdx_mod.UNet(cfg, params)
+    tiles = [cdx_mod._abi.lib().cdx_conv_select_tile(ctypes.byref(a)) for fn, a, _, _ in net.plan(2).calls
+             if fn.__name__ == "cdx_conv_f32" and a.ksize == 3]
+    assert tiles.count(7) >= len(tiles) // 2, tiles
+    got = cdx_mod.Sampler(net).sample(cond.cuda(), 10, seed=12).cpu()
+    want = oracle.sample_ref(cfg, params, cond, 10, seed=12)
+    record("sampler_winograd_live", psnr_hip_vs_oracle=psnr(got, want), dpsnr=abs(psnr(got, tgt) - psnr(want, tgt)),
+           winograd_layers=tiles.count(7), conv3x3_layers=len(tiles))
+    assert psnr(got, want) >= 80.0 and abs(psnr(got, tgt) - psnr(want, tgt)) <= 0.01
 
 
 def test_sampler_ddpm_golden(cdx_mod, record):
