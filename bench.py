@@ -108,6 +108,15 @@ def measure_dominant_kernel(plan, torch, reps=3):
             "executed_tflops": round(executed, 2), "executed_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
             "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_forward": d["launches"] // reps,
             "flop_share_of_forward": round(d["flops"] / sum(v["flops"] for v in table.values()), 4)}
+    # HBM bytes per launch of this kernel: PMC counters cannot be read from inside the process, so the figure
+    # comes from the committed rocprofv3 --pmc passes over this same command (profiles/r01_traffic.json).
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if wino and "wino" in tr["kernel"]:
+            roof["traffic"] = round(tr["hbm_bytes_per_launch"])
+            roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2 x FETCH + WRITE)"
+    except (OSError, KeyError, ValueError):
+        pass
     per_variant = {"k%ds%d_tw%d_%s" % k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                          "ms_per_forward": round(v["ms"] / reps, 3)}
                    for k, v in sorted(table.items(), key=lambda kv: -kv[1]["flops"])}
@@ -241,13 +250,16 @@ def main():
     fl = plan_flops(plan)
     total_flops = sum(fl.values())
     line = {
-        "metric": "decoded images/sec (whole node), 256x256 100-step DDIM",
+        "metric": ("decoded images/sec (whole node), 256x256 100-step DDIM" if args.config in ("cfg2", "cfg3") else
+                   f"decoded images/sec (whole node), {args.config}: {cfg['image_size']}x{cfg['image_size']} {run['steps']}-step {run['method'].upper()}"),
         "value": round(images_per_s, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[1]: 256x256x3, 128-ch UNet (channel_mult 1,1,2,2,4,4; "
-                               f"self-attn at 16^2), {run['steps']}-step {run['method'].upper()}, batch {B} per GPU, "
-                               f"seeded random weights (cdx.init_params seed 0)",
+        "config": {"workload": (f"BASELINE.json configs[1]: 256x256x3, 128-ch UNet (channel_mult 1,1,2,2,4,4; "
+                                f"self-attn at 16^2), {run['steps']}-step {run['method'].upper()}, batch {B} per GPU, "
+                                f"seeded random weights (cdx.init_params seed 0)") if args.config in ("cfg2", "cfg3") else
+                               (f"BASELINE.json {args.config}: {cfg['image_size']}^2 x3, {cfg['base_channels']}-ch UNet, "
+                                f"cond_mode {cfg['cond_mode']}, {run['steps']}-step {run['method'].upper()}, batch {B} per GPU"),
                    "images_per_gpu": B, "global_batch": B * world, "image": f"{cfg['image_size']}x{cfg['image_size']}x3",
                    "sampler_steps_per_image": run["steps"], "parallelism": f"replica x{world} (no collective)"},
         "algorithmic_gflop_per_step": round(total_flops / 1e9, 1),
