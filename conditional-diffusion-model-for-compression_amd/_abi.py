@@ -78,6 +78,11 @@ class ExportImageArgs(C.Structure):
                 ("lo", C.c_float), ("hi", C.c_float), ("out", _f)]
 
 
+class TileBlendArgs(C.Structure):
+    _fields_ = [("tiles", _f), ("batch", _i), ("channels", _i), ("tile", _i), ("ny", _i), ("nx", _i),
+                ("y0", _f), ("x0", _f), ("h", _i), ("w", _i), ("out", _f)]
+
+
 # op name -> args struct; every op has cdx_<op>(args*, ws, ws_bytes, stream) and cdx_<op>_workspace(args*)
 OPS = {
     "conv_f32": ConvArgs,
@@ -90,6 +95,7 @@ OPS = {
     "gauss_fill_f32": GaussFillArgs,
     "cond_embed_f32": CondEmbedArgs,
     "export_image_f32": ExportImageArgs,
+    "tile_blend_f32": TileBlendArgs,
 }
 
 # every exported symbol include/cdx.h declares (checked by tests/test_abi.py without a GPU)

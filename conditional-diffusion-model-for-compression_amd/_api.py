@@ -10,7 +10,8 @@ __all__ = ["unet_config", "validate_unet_config", "named_config", "UNET_DEFAULTS
            "build_graph", "init_params", "synthetic_batch", "rng"]
 from .unet import UNet
 from .sampler import Sampler, sample
-from . import ops, _abi, shard, params
+from . import ops, _abi, shard, params, tiling
+from .tiling import tile_plan, tile_origins
 from .shard import shard_range, decode_shard, timed_region
 
-__all__ += ["UNet", "Sampler", "sample", "ops", "_abi", "shard", "params", "shard_range", "decode_shard", "timed_region"]
+__all__ += ["UNet", "Sampler", "sample", "ops", "_abi", "shard", "params", "shard_range", "decode_shard", "timed_region", "tiling", "tile_plan", "tile_origins"]

@@ -94,6 +94,39 @@ __global__ __launch_bounds__(256) void timestep_embedding_kernel(const int32_t* 
     out[(size_t)b * dim + half + k] = (float)cos(arg);
 }
 
+// S5: per output pixel, the (at most 2 x 2) tiles that cover it, separable linear ramps over the overlaps.
+__device__ __forceinline__ float ramp_weight(int u, int tile, int ov_lo, int ov_hi) {
+    const float a = fminf(1.f, ((float)u + 0.5f) / (float)ov_lo);
+    const float b = fminf(1.f, ((float)(tile - u) - 0.5f) / (float)ov_hi);
+    return a * b;
+}
+
+__global__ __launch_bounds__(256) void tile_blend_kernel(const float* __restrict__ tiles, int channels, int tile, int ny,
+                                                         int nx, const int* __restrict__ y0, const int* __restrict__ x0,
+                                                         int h, int w, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < h * w; p += gridDim.x * blockDim.x) {
+        const int y = p / w, x = p - y * w;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f}, wsum = 0.f;      // channels <= 4
+        for (int iy = 0; iy < ny; ++iy) {
+            const int u = y - y0[iy];
+            if (u < 0 || u >= tile) continue;
+            const int ovl = iy > 0 ? max(1, y0[iy - 1] + tile - y0[iy]) : 1, ovh = iy + 1 < ny ? max(1, y0[iy] + tile - y0[iy + 1]) : 1;
+            const float wy = ramp_weight(u, tile, ovl, ovh);
+            for (int ix = 0; ix < nx; ++ix) {
+                const int v = x - x0[ix];
+                if (v < 0 || v >= tile) continue;
+                const int oxl = ix > 0 ? max(1, x0[ix - 1] + tile - x0[ix]) : 1, oxh = ix + 1 < nx ? max(1, x0[ix] + tile - x0[ix + 1]) : 1;
+                const float wt = wy * ramp_weight(v, tile, oxl, oxh);
+                const float* t = tiles + ((((size_t)b * ny + iy) * nx + ix) * channels) * tile * tile + (size_t)u * tile + v;
+                for (int c = 0; c < channels; ++c) acc[c] += wt * t[(size_t)c * tile * tile];
+                wsum += wt;
+            }
+        }
+        for (int c = 0; c < channels; ++c) out[((size_t)b * channels + c) * h * w + p] = acc[c] / wsum;
+    }
+}
+
 inline dim3 pixel_grid(int hw, int batch) {
     int gx = (hw + 255) / 256;
     if (gx > 2048) gx = 2048;
@@ -145,5 +178,15 @@ extern "C" int cdx_timestep_embedding_f32(const cdx_timestep_embedding_args* a, 
     const int n = a->batch * (a->dim / 2);
     hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
                        a->t, a->batch, a->dim, a->out);
+    return check_launch();
+}
+
+extern "C" size_t cdx_tile_blend_f32_workspace(const cdx_tile_blend_args*) { return 0; }
+extern "C" int cdx_tile_blend_f32(const cdx_tile_blend_args* a, void*, size_t, cdx_stream_t stream) {
+    CDX_REQUIRE(a && a->tiles && a->y0 && a->x0 && a->out);
+    CDX_REQUIRE(a->batch > 0 && a->batch <= 65535 && a->channels > 0 && a->channels <= 4 && a->tile > 0);
+    CDX_REQUIRE(a->ny > 0 && a->nx > 0 && a->h >= a->tile && a->w >= a->tile);
+    hipLaunchKernelGGL(tile_blend_kernel, pixel_grid(a->h * a->w, a->batch), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       a->tiles, a->channels, a->tile, a->ny, a->nx, a->y0, a->x0, a->h, a->w, a->out);
     return check_launch();
 }

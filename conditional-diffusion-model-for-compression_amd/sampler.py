@@ -30,10 +30,11 @@ class Sampler:
 
     @torch.no_grad()
     def sample(self, cond: torch.Tensor, steps: int, *, seed: int = 0, first_image: int = 0,
-               trace: list | None = None) -> torch.Tensor:
+               trace: list | None = None, x_T: torch.Tensor | None = None) -> torch.Tensor:
         """cond [B,Cc,hc,wc] or [B,L,D] -> x_0 [B,C,H,W] in [-1,1] on the UNet's device.
 
         `first_image` is the global index of cond[0] (noise streams are keyed by global index).
+        `x_T` [B,C,H,W], if given, replaces the generator's x_T (tiled decode: crops of one noise field).
         """
         net, cfg = self.unet, self.unet.cfg
         B, C = cond.shape[0], cfg["in_channels"]
@@ -41,7 +42,10 @@ class Sampler:
         coefs = step_coefficients(self.schedule, steps, self.method)
         st = torch.cuda.current_stream().cuda_stream
         load_cond(p, cfg, cond)
-        ops.gauss_fill(p.xin, C, seed, first_image, STREAM_XT)
+        if x_T is None:
+            ops.gauss_fill(p.xin, C, seed, first_image, STREAM_XT)
+        else:
+            p.xin[..., :C] = x_T.to(net.device, torch.float32).permute(0, 2, 3, 1)
         upd = _abi.DiffusionUpdateArgs()
         upd.x, upd.x_ld, upd.eps, upd.eps_ld = p.xin.data_ptr(), p.xin.shape[-1], p.eps.data_ptr(), p.eps.shape[-1]
         upd.batch, upd.hw, upd.channels = B, p.xin.shape[1] * p.xin.shape[2], C
@@ -58,6 +62,12 @@ class Sampler:
             if trace is not None:
                 trace.append(p.xin[..., :C].permute(0, 3, 1, 2).clone())
         return ops.export_image(p.xin, C, -1.0, 1.0)
+
+
+    def sample_tiled(self, cond: torch.Tensor, steps: int, **kw) -> torch.Tensor:
+        """Decode an image larger than the UNet's native size tile by tile (tiling.py, S5)."""
+        from .tiling import sample_tiled
+        return sample_tiled(self, cond, steps, **kw)
 
 
 def sample(unet: UNet, cond: torch.Tensor, steps: int, *, method: str = "ddim", schedule: dict | None = None,

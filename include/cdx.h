@@ -257,6 +257,24 @@ typedef struct cdx_export_image_args {
 int cdx_export_image_f32(const cdx_export_image_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
 size_t cdx_export_image_f32_workspace(const cdx_export_image_args* a);
 
+/* S5: blend decoded tiles into the full image.  tiles NCHW [batch*ny*nx, channels, tile, tile] (image-major, then
+ * tile row, then tile column); tile (iy, ix) covers rows [y0[iy], y0[iy]+tile), columns [x0[ix], x0[ix]+tile).
+ * out[b][c][y][x] = sum_t w_t(y,x) tile_t / sum_t w_t(y,x) with separable weights: along each axis
+ * w(u) = min(1, (u+0.5)/ov_lo) * min(1, (tile-u-0.5)/ov_hi), u = local coordinate, ov_lo / ov_hi = overlap with the
+ * previous / next tile (1 = no ramp at an image border). */
+typedef struct cdx_tile_blend_args {
+    const float* tiles;
+    int32_t batch, channels, tile;
+    int32_t ny, nx;
+    const int32_t* y0; /* [ny] device */
+    const int32_t* x0; /* [nx] device */
+    int32_t h, w;      /* full image size */
+    float* out;        /* NCHW [batch, channels, h, w] */
+} cdx_tile_blend_args;
+
+int cdx_tile_blend_f32(const cdx_tile_blend_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_tile_blend_f32_workspace(const cdx_tile_blend_args* a);
+
 /* Diagnostics: monotonically counts kernel launches made through this library (relaxed atomic;
  * the only process-global the library keeps, used by tests to prove the HIP path ran). */
 uint64_t cdx_launch_count(void);

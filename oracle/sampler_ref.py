@@ -60,13 +60,14 @@ def noise_ref(seed: int, first_image: int, count: int, stream: int, shape) -> to
 
 def sample_ref(cfg: dict, params: dict, cond: torch.Tensor, steps: int, *, seed: int = 0,
                method: str = "ddim", clip_x0: bool = True, first_image: int = 0,
-               dtype=torch.float32, schedule: dict | None = None, trace: list | None = None) -> torch.Tensor:
+               dtype=torch.float32, schedule: dict | None = None, trace: list | None = None,
+               x_T: torch.Tensor | None = None) -> torch.Tensor:
     sc = dict(T=1000, beta_start=1e-4, beta_end=2e-2)
     sc.update({k: v for k, v in (schedule or {}).items() if k in sc})
     B = cond.shape[0]
     H = cfg["image_size"]
     shape = (cfg["in_channels"], H, H)
-    x = noise_ref(seed, first_image, B, 1, shape).to(dtype)
+    x = (noise_ref(seed, first_image, B, 1, shape) if x_T is None else x_T).to(dtype)
     for k, (t, ca, cb, cx, c0, ce, sigma) in enumerate(step_coefficients_ref(steps, method, **sc)):
         tt = torch.full((B,), t, dtype=torch.int64)
         eps = unet_forward_ref(cfg, params, x, tt, cond, dtype=dtype)

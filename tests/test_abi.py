@@ -32,7 +32,7 @@ def test_struct_layouts_match_c(tmp_path):
     structs = {"cdx_conv_args": A.ConvArgs, "cdx_gn_stats_args": A.GnStatsArgs, "cdx_gn_finalize_args": A.GnFinalizeArgs, "cdx_attn_args": A.AttnArgs,
                "cdx_linear_args": A.LinearArgs, "cdx_timestep_embedding_args": A.TimestepEmbeddingArgs,
                "cdx_diffusion_update_args": A.DiffusionUpdateArgs, "cdx_gauss_fill_args": A.GaussFillArgs,
-               "cdx_cond_embed_args": A.CondEmbedArgs, "cdx_export_image_args": A.ExportImageArgs}
+               "cdx_cond_embed_args": A.CondEmbedArgs, "cdx_export_image_args": A.ExportImageArgs, "cdx_tile_blend_args": A.TileBlendArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -121,3 +121,16 @@ def test_synthetic_batch_keyed_by_global_index():
     whole, part = cdx.synthetic_batch(cfg, 9, 0, 4), cdx.synthetic_batch(cfg, 9, 2, 2)
     assert np.array_equal(whole["cond"][2:], part["cond"]) and np.array_equal(whole["target"][2:], part["target"])
     assert whole["cond"].shape == (4, 3, 2, 2) and np.abs(whole["target"]).max() <= 1
+
+
+def test_tile_plan_matches_survey_and_oracle():
+    import oracle
+    ys, xs = cdx.tile_plan(1024, 1024, 256, 64)
+    assert ys == xs == [0, 192, 384, 576, 768] and len(ys) * len(xs) == 25          # 25 tiles with 64-px overlap
+    assert cdx.tile_plan(1024, 1024, 256, 0)[0] == [0, 256, 512, 768]                # 16 tiles without overlap
+    assert cdx.tile_origins(80, 32, 16) == [0, 16, 32, 48] == oracle.origins_ref(80, 32, 16)
+    assert cdx.tile_origins(256, 256, 64) == [0]
+    with pytest.raises(ValueError):
+        cdx.tile_origins(80, 32, 8)        # origins 24, 48 are not multiples of the conditioning stride
+    with pytest.raises(ValueError):
+        cdx.tile_origins(16, 32, 0)
