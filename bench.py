@@ -189,7 +189,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run: RCCL for the barrier / max-reduce only
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
