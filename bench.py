@@ -33,6 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)" (spec; 155 measured)
+FP16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
 def conv_variant(a) -> tuple:
@@ -40,6 +41,8 @@ def conv_variant(a) -> tuple:
     import ctypes
     import cdx
     logtw = 5 if a.wout >= 32 else 4 if a.wout >= 16 else 3 if a.wout >= 8 else 2
+    if isinstance(a, cdx._abi.ConvF16Args):
+        return (a.ksize, a.stride, logtw, "f16_64x128" if a.stride == 2 else "f16_128x128")
     tile = cdx._abi.lib().cdx_conv_select_tile(ctypes.byref(a))
     return (a.ksize, a.stride, logtw, cdx._abi.TILE_NAMES[tile])
 
@@ -53,9 +56,9 @@ def plan_flops(plan) -> dict:
     out = {"conv": 0.0, "attn": 0.0, "linear": 0.0}
     for fn, a, _, _ in plan.calls:
         n = fn.__name__
-        if n == "cdx_conv_f32":
+        if n in ("cdx_conv_f32", "cdx_conv_f16"):
             out["conv"] += conv_flops(a)
-        elif n == "cdx_attn_f32":
+        elif n in ("cdx_attn_f32", "cdx_attn_f16"):
             out["attn"] += 4.0 * a.batch * a.heads * a.nq * a.nk * a.head_dim
         elif n == "cdx_linear_f32":
             out["linear"] += 2.0 * a.m * a.n * a.k
@@ -72,7 +75,7 @@ def measure_dominant_kernel(plan, torch, reps=3):
     for rep in range(reps + 1):
         evs = []
         for i, (fn, a, wp, wb) in enumerate(plan.calls):
-            if fn.__name__ == "cdx_conv_f32":
+            if fn.__name__ in ("cdx_conv_f32", "cdx_conv_f16"):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(st)
                 fn(ctypes.byref(a), wp, wb, st.cuda_stream)
@@ -96,16 +99,19 @@ def measure_dominant_kernel(plan, torch, reps=3):
     d = table[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     wino = dom[3].startswith("wino")
+    half = dom[3].startswith("f16")
+    peak = FP16_MFMA_PEAK_TFLOPS if half else FP32_MFMA_PEAK_TFLOPS
     # Winograd F(2x2,3x3) issues 16 multiply-adds where the direct algorithm (which `achieved` counts) needs 36.
     executed = achieved / 2.25 if wino else achieved
-    roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+    roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
             "kernel": ("conv_wino_kernel<WinoCfg> (Winograd F(2x2,3x3), ksize %d stride %d log2TW %d tile %s)" if wino else
+                       "conv16_kernel<Conv16Cfg> (fp16 MFMA, ksize %d stride %d log2TW %d tile %s)" if half else
                        "conv_kernel<ConvCfg<ksize %d, stride %d, log2TW %d, tile %s>>") % dom,
             "flop_accounting": "achieved = ALGORITHMIC direct-convolution FLOPs (2*Cin*Cout*9*H*W*B) / measured time"
                                + ("; this kernel is Winograd F(2x2,3x3): it issues 2.25x fewer MFMA FLOPs than that, so "
                                   "frac can exceed 1; executed_* is the MFMA work actually issued" if wino else ""),
-            "executed_tflops": round(executed, 2), "executed_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
+            "executed_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4),
             "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_forward": d["launches"] // reps,
             "flop_share_of_forward": round(d["flops"] / sum(v["flops"] for v in table.values()), 4)}
     # HBM bytes per launch of this kernel: PMC counters cannot be read from inside the process, so the figure
@@ -196,6 +202,10 @@ def main():
 
     cfg, run = cdx.named_config(args.config)
     B = args.batch
+    # cfg5: the unit of work of a step is a batch of 256^2 TILES (fp16); an image is (image/stride)^2 tiles
+    tiles_per_image = 1
+    if "image" in run:
+        tiles_per_image = len(cdx.tile_origins(run["image"], cfg["image_size"], run["overlap"])) ** 2
     params = cdx.init_params(cfg, seed=0)
     net = cdx.UNet(cfg, params, device=f"cuda:{local}")
     sampler = cdx.Sampler(net, method=run["method"])
@@ -246,7 +256,7 @@ def main():
     assert torch.isfinite(plan.xin).all(), "non-finite state after the timed region"
 
     ms_per_step = elapsed / args.steps * 1e3
-    images_per_s = (B * world) / (run["steps"] * ms_per_step * 1e-3)
+    images_per_s = (B * world / tiles_per_image) / (run["steps"] * ms_per_step * 1e-3)
     fl = plan_flops(plan)
     total_flops = sum(fl.values())
     line = {
@@ -254,12 +264,14 @@ def main():
                    f"decoded images/sec (whole node), {args.config}: {cfg['image_size']}x{cfg['image_size']} {run['steps']}-step {run['method'].upper()}"),
         "value": round(images_per_s, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f16" if cfg["dtype"] == "fp16" else "f32", "data": "synthetic",
         "config": {"workload": (f"BASELINE.json configs[1]: 256x256x3, 128-ch UNet (channel_mult 1,1,2,2,4,4; "
                                 f"self-attn at 16^2), {run['steps']}-step {run['method'].upper()}, batch {B} per GPU, "
                                 f"seeded random weights (cdx.init_params seed 0)") if args.config in ("cfg2", "cfg3") else
-                               (f"BASELINE.json {args.config}: {cfg['image_size']}^2 x3, {cfg['base_channels']}-ch UNet, "
-                                f"cond_mode {cfg['cond_mode']}, {run['steps']}-step {run['method'].upper()}, batch {B} per GPU"),
+                               (f"BASELINE.json {args.config}: {cfg['image_size']}^2 x3, {cfg['base_channels']}-ch UNet, dtype "
+                                f"{cfg['dtype']}, cond_mode {cfg['cond_mode']}, {run['steps']}-step {run['method'].upper()}, "
+                                f"batch {B} per GPU" + (f" = tiles of a {run['image']}^2 image ({tiles_per_image} tiles/image, "
+                                                       f"overlap {run['overlap']})" if tiles_per_image > 1 else "")),
                    "images_per_gpu": B, "global_batch": B * world, "image": f"{cfg['image_size']}x{cfg['image_size']}x3",
                    "sampler_steps_per_image": run["steps"], "parallelism": f"replica x{world} (no collective)"},
         "algorithmic_gflop_per_step": round(total_flops / 1e9, 1),
@@ -271,7 +283,7 @@ def main():
         if args.details:
             print(json.dumps({"conv_variants": table, "flops": fl}, indent=1), file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(cfg, params, torch.from_numpy(sb["cond"]), torch)
+        line["cpu_baseline"] = cpu_baseline(dict(cfg, dtype="fp32"), params, torch.from_numpy(sb["cond"]), torch)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -28,6 +28,15 @@ class ConvArgs(C.Structure):
                 ("temb", _f), ("temb_ld", _i), ("residual", _f), ("out", _f), ("out_ld", _i), ("wpacked_wino", _f), ("stats_out", _f)]
 
 
+class ConvF16Args(C.Structure):
+    _fields_ = [("src0", _f), ("src1", _f), ("c0", _i), ("c1", _i), ("src_is_f32", _i),
+                ("batch", _i), ("hin", _i), ("win", _i), ("hout", _i), ("wout", _i),
+                ("cout", _i), ("ksize", _i), ("stride", _i), ("flags", _i),
+                ("wpacked", _f), ("bias", _f), ("gn_scale", _f), ("gn_shift", _f),
+                ("temb", _f), ("temb_ld", _i), ("residual", _f), ("out", _f), ("out_is_f32", _i), ("out_ld", _i),
+                ("stats_out", _f)]
+
+
 class GnStatsArgs(C.Structure):
     _fields_ = [("src0", _f), ("src1", _f), ("c0", _i), ("c1", _i), ("batch", _i), ("hw", _i),
                 ("groups", _i), ("eps", C.c_float), ("gamma", _f), ("beta", _f),
@@ -86,6 +95,8 @@ class TileBlendArgs(C.Structure):
 # op name -> args struct; every op has cdx_<op>(args*, ws, ws_bytes, stream) and cdx_<op>_workspace(args*)
 OPS = {
     "conv_f32": ConvArgs,
+    "conv_f16": ConvF16Args,
+    "attn_f16": AttnArgs,
     "gn_stats_f32": GnStatsArgs,
     "gn_finalize_f32": GnFinalizeArgs,
     "attn_f32": AttnArgs,
@@ -103,7 +114,8 @@ TILE_NAMES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "64x128", 4: "64x64", 5
 
 EXPORTS = (["cdx_abi_version", "cdx_strerror", "cdx_launch_count",
             "cdx_conv_packed_floats", "cdx_conv_pack_weights_f32", "cdx_conv_select_tile", "cdx_conv_f32_tile",
-            "cdx_conv_stats_slots", "cdx_conv_wino_packed_floats", "cdx_conv_pack_weights_wino_f32"]
+            "cdx_conv_stats_slots", "cdx_conv_wino_packed_floats", "cdx_conv_pack_weights_wino_f32",
+            "cdx_conv_f16_stats_slots", "cdx_conv_f16_packed_halves", "cdx_conv_pack_weights_f16"]
            + [f"cdx_{op}" for op in OPS] + [f"cdx_{op}_workspace" for op in OPS])
 
 _lib = None
@@ -136,6 +148,12 @@ def lib() -> C.CDLL:
     L.cdx_conv_wino_packed_floats.argtypes = [_i, _i, _i]
     L.cdx_conv_pack_weights_wino_f32.restype = C.c_int
     L.cdx_conv_pack_weights_wino_f32.argtypes = [_f, _i, _i, _i, _f]
+    L.cdx_conv_f16_stats_slots.restype = C.c_int32
+    L.cdx_conv_f16_stats_slots.argtypes = [C.POINTER(ConvF16Args)]
+    L.cdx_conv_f16_packed_halves.restype = C.c_size_t
+    L.cdx_conv_f16_packed_halves.argtypes = [_i, _i, _i, _i]
+    L.cdx_conv_pack_weights_f16.restype = C.c_int
+    L.cdx_conv_pack_weights_f16.argtypes = [_f, _i, _i, _i, _i, _f]
     L.cdx_conv_select_tile.restype = C.c_int
     L.cdx_conv_select_tile.argtypes = [C.POINTER(ConvArgs)]
     L.cdx_conv_stats_slots.restype = C.c_int32
@@ -193,4 +211,18 @@ def pack_conv_weights_wino(w_oihw, c0: int, c1: int):
     n = int(lib().cdx_conv_wino_packed_floats(c0, c1, cout))
     out = np.empty(n, np.float32)
     check(lib().cdx_conv_pack_weights_wino_f32(w.ctypes.data, c0, c1, cout, out.ctypes.data), "cdx_conv_pack_weights_wino_f32")
+    return out
+
+
+def pack_conv_weights_f16(w_oihw, c0: int, c1: int):
+    """numpy OIHW float32 -> fp16 fragment image as numpy float16 (host)."""
+    import numpy as np
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    cout, cin, k, _ = w.shape
+    assert cin == c0 + c1
+    n = int(lib().cdx_conv_f16_packed_halves(c0, c1, cout, k))
+    if n == 0:
+        raise CdxError("cdx_conv_f16_packed_halves: bad arguments")
+    out = np.empty(n, np.float16)
+    check(lib().cdx_conv_pack_weights_f16(w.ctypes.data, c0, c1, cout, k, out.ctypes.data), "cdx_conv_pack_weights_f16")
     return out

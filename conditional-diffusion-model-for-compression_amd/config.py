@@ -48,8 +48,8 @@ def validate_unet_config(cfg: dict) -> dict:
     ch, g = cfg["base_channels"], cfg["groups"]
     if cfg["cond_mode"] not in ("concat", "cross_attn"):
         raise ValueError(f"cond_mode must be 'concat' or 'cross_attn', got {cfg['cond_mode']!r}")
-    if cfg["dtype"] not in ("fp32",):
-        raise ValueError(f"dtype {cfg['dtype']!r} is not built yet (fp32 only this round)")
+    if cfg["dtype"] not in ("fp32", "fp16"):
+        raise ValueError(f"dtype must be 'fp32' or 'fp16', got {cfg['dtype']!r}")
     nlev = len(cfg["channel_mult"])
     if cfg["image_size"] % (1 << (nlev - 1)):
         raise ValueError("image_size must be divisible by 2**(levels-1)")
@@ -70,8 +70,7 @@ def validate_unet_config(cfg: dict) -> dict:
 def named_config(name: str) -> tuple[dict, dict]:
     """(unet_cfg, run_cfg) for BASELINE.json configs[0..4] ("cfg1".."cfg5").
 
-    run_cfg: batch, steps, method.  cfg5 (fp16, tiled 1024^2) is declared but its
-    dtype is not built this round.
+    run_cfg: batch, steps, method (cfg5 also: image = full image side, decoded as 256^2 tiles).
     """
     if name == "cfg1":   # 32x32x3 CIFAR-shaped, 64-ch UNet, 50 DDIM steps, batch 1
         return (unet_config(image_size=32, base_channels=64, channel_mult=(1, 2, 2, 2),
@@ -85,4 +84,7 @@ def named_config(name: str) -> tuple[dict, dict]:
                             attn_resolutions=(16,), cross_attn_resolutions=(32, 16),
                             context_dim=320),
                 dict(batch=8, steps=250, method="ddpm"))
+    if name == "cfg5":   # 1024x1024x3 tiled decode through the 256^2 UNet, fp16 storage / fp16 MFMA, 50 DDIM steps
+        return (unet_config(dtype="fp16"),
+                dict(batch=64, steps=50, method="ddim", image=1024, overlap=64))
     raise KeyError(name)

@@ -11,6 +11,8 @@
 // probability tile already has the MFMA A-operand layout of the P V product -- it never leaves
 // registers (cdna guide, "An accumulator tile as the next MFMA's operand").
 // No reference file exists to cite (reference snapshot is empty); semantics = softmax(q k^T * scale) v.
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 using namespace cdx;
@@ -20,16 +22,29 @@ namespace {
 constexpr int HD = 64;
 constexpr int KSTR = HD + 4;   // padded K row: conflict-free ds_read_b128 across 16 keys
 
+// T = float or _Float16: storage type of q / k / v / out (arithmetic is float32 either way)
+template <typename T>
+__device__ __forceinline__ f32x4 ld4(const T* p) {
+    if constexpr (sizeof(T) == 4) return *reinterpret_cast<const f32x4*>(p);
+    else {
+        using h4 = __attribute__((ext_vector_type(4))) _Float16;
+        const h4 v = *reinterpret_cast<const h4*>(p);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+}
+
+template <typename T>
 struct AttnParams {
-    const float *q, *k, *v;
+    const T *q, *k, *v;
     int q_ld, k_ld, v_ld;
     int nq, nk;
     float scale;
-    float* out;
+    T* out;
     int out_ld;
 };
 
-__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+template <typename T>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnParams<T> p) {
     __shared__ __attribute__((aligned(16))) float smem[32 * KSTR + 32 * HD];
     float* Ks = smem;
     float* Vs = smem + 32 * KSTR;
@@ -43,10 +58,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     f32x4 qf[8];
     {
         const int row = min(qb + li, p.nq - 1);
-        const float* src = p.q + ((size_t)b * p.nq + row) * p.q_ld + head * HD + lh * 32;
+        const T* src = p.q + ((size_t)b * p.nq + row) * p.q_ld + head * HD + lh * 32;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            qf[i] = *reinterpret_cast<const f32x4*>(src + i * 4);
+            qf[i] = ld4(src + i * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) qf[i][e] *= p.scale;
         }
@@ -55,13 +70,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const int skey = tid >> 3, sd = (tid & 7) * 8;   // staging: key row, first of 8 floats
     auto stage = [&](int kb, bool with_v) {
         const int krow = min(kb + skey, p.nk - 1);
-        const float* ks = p.k + ((size_t)b * p.nk + krow) * p.k_ld + head * HD + sd;
-        const f32x4 k0 = *reinterpret_cast<const f32x4*>(ks), k1 = *reinterpret_cast<const f32x4*>(ks + 4);
+        const T* ks = p.k + ((size_t)b * p.nk + krow) * p.k_ld + head * HD + sd;
+        const f32x4 k0 = ld4(ks), k1 = ld4(ks + 4);
         *reinterpret_cast<f32x4*>(Ks + skey * KSTR + sd) = k0;
         *reinterpret_cast<f32x4*>(Ks + skey * KSTR + sd + 4) = k1;
         if (with_v) {
-            const float* vs = p.v + ((size_t)b * p.nk + krow) * p.v_ld + head * HD + sd;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(vs), v1 = *reinterpret_cast<const f32x4*>(vs + 4);
+            const T* vs = p.v + ((size_t)b * p.nk + krow) * p.v_ld + head * HD + sd;
+            const f32x4 v0 = ld4(vs), v1 = ld4(vs + 4);
             *reinterpret_cast<f32x4*>(Vs + skey * HD + sd) = v0;
             *reinterpret_cast<f32x4*>(Vs + skey * HD + sd + 4) = v1;
         }
@@ -132,27 +147,32 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         const int qrow = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const float inv = __shfl(linv, qrow);
         if (qb + qrow < p.nq) {
-            float* o = p.out + ((size_t)b * p.nq + qb + qrow) * p.out_ld + head * HD + li;
-            o[0] = oacc[0][r] * inv;
-            o[32] = oacc[1][r] * inv;
+            T* o = p.out + ((size_t)b * p.nq + qb + qrow) * p.out_ld + head * HD + li;
+            o[0] = (T)(oacc[0][r] * inv);
+            o[32] = (T)(oacc[1][r] * inv);
         }
     }
 }
 
-}  // namespace
-
-extern "C" size_t cdx_attn_f32_workspace(const cdx_attn_args*) { return 0; }
-
-extern "C" int cdx_attn_f32(const cdx_attn_args* a, void*, size_t, cdx_stream_t stream) {
+template <typename T>
+int attn_launch(const cdx_attn_args* a, cdx_stream_t stream) {
     CDX_REQUIRE(a && a->q && a->k && a->v && a->out);
     CDX_REQUIRE(a->batch > 0 && a->batch <= 65535 && a->heads > 0 && a->heads <= 65535 && a->nq > 0 && a->nk > 0);
     if (a->head_dim != HD) return CDX_ENOTSUP;
     const int c = a->heads * HD;
     CDX_REQUIRE(a->q_ld >= c && a->k_ld >= c && a->v_ld >= c && a->out_ld >= c);
     CDX_REQUIRE((a->q_ld % 4) == 0 && (a->k_ld % 4) == 0 && (a->v_ld % 4) == 0);
-    CDX_REQUIRE(aligned16(a->q) && aligned16(a->k) && aligned16(a->v));
-    AttnParams p{a->q, a->k, a->v, a->q_ld, a->k_ld, a->v_ld, a->nq, a->nk, a->scale, a->out, a->out_ld};
-    hipLaunchKernelGGL(attn_kernel, dim3((a->nq + 127) / 128, a->heads, a->batch), dim3(256), 0,
+    CDX_REQUIRE(aligned16(a->q) && ((uintptr_t)a->k % 8) == 0 && ((uintptr_t)a->v % 8) == 0);
+    AttnParams<T> p{reinterpret_cast<const T*>(a->q), reinterpret_cast<const T*>(a->k), reinterpret_cast<const T*>(a->v),
+                    a->q_ld, a->k_ld, a->v_ld, a->nq, a->nk, a->scale, reinterpret_cast<T*>(a->out), a->out_ld};
+    hipLaunchKernelGGL(attn_kernel<T>, dim3((a->nq + 127) / 128, a->heads, a->batch), dim3(256), 0,
                        static_cast<hipStream_t>(stream), p);
     return check_launch();
 }
+
+}  // namespace
+
+extern "C" size_t cdx_attn_f32_workspace(const cdx_attn_args*) { return 0; }
+extern "C" int cdx_attn_f32(const cdx_attn_args* a, void*, size_t, cdx_stream_t stream) { return attn_launch<float>(a, stream); }
+extern "C" size_t cdx_attn_f16_workspace(const cdx_attn_args*) { return 0; }
+extern "C" int cdx_attn_f16(const cdx_attn_args* a, void*, size_t, cdx_stream_t stream) { return attn_launch<_Float16>(a, stream); }

@@ -1,0 +1,285 @@
+// fp16-storage convolution: implicit GEMM on v_mfma_f32_32x32x16_f16 (fp16 operands, fp32 accumulate).
+// BASELINE.json configs[4] ("fp16 UNet on CDNA4 MFMA"); SURVEY.md section 8(a) U3/U4 "_f16 variants".
+//
+// Same structure as conv_kernel.h -- a TH x TW pixel rectangle x 128 output channels per workgroup; per
+// 32-channel chunk the input halo is gathered to LDS once with GroupNorm scale/shift (fp32), SiLU, nearest-2x
+// upsampling and channel concat applied on the way and rounded to fp16; every tap reads its A fragments from that one
+// image; weights come fragment-packed from L2 through a prefetch ring; bias/temb/residual/GroupNorm partial sums in the
+// epilogue -- with the differences the 16x faster matrix instruction forces:
+//   * one MFMA consumes 16 channels: lane (row i = lane&31, half h = lane>>5) supplies channels 8h..8h+7 of the
+//     16-channel step as ONE 16-byte LDS read (A) / ONE 16-byte global load (B); two MFMAs per (tap, chunk, M-tile);
+//   * LDS image in fp16: pixel stride 40 halves (32 + 8 pad = 80 B: ds_read_b128 lane groups hit 16 distinct 4-bank
+//     slots), row stride a multiple of 256 B;
+//   * sources may be fp32 (the sampler's x_t buffer feeding conv_in) or fp16; the output fp16 or fp32 (conv_out);
+//   * GroupNorm statistics are taken from the fp32 accumulators BEFORE rounding (GN stays fp32).
+// The kernel is no longer MFMA-bound (36.9k -> 2.3k MFMA cycles per chunk): the staging VALU, LDS reads and the
+// L2 weight stream set its speed.
+#pragma once
+#include <hip/hip_fp16.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace cdx {
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+struct Conv16Params {
+    const void* src[2];
+    int csrc[2];
+    int src_f32;     // sources are float32 (else float16)
+    int nchunk0, nchunks, ctot;
+    int B, Hin, Win, Hout, Wout, Cout;
+    int ups, gn, silu;
+    const _Float16* w;
+    const float* bias;
+    const float* gscale;
+    const float* gshift;
+    const float* temb;
+    int temb_ld;
+    const _Float16* residual;
+    void* out;
+    int out_f32;
+    int out_ld;
+    double* stats;
+    int tiles_x, tiles_y;
+};
+
+template <int KS_, int STRIDE_, int LOGTW_, int MT_, int PF_ = 3>
+struct Conv16Cfg {
+    static constexpr int KS = KS_, STRIDE = STRIDE_, LOGTW = LOGTW_, MT = MT_, PF = PF_;
+    static constexpr int KC = 32, PSH = KC + 8;                    // pixel stride in halves
+    static constexpr int TAPS = KS * KS, PAD = KS / 2;
+    static constexpr int TW = 1 << LOGTW;
+    static constexpr int BM = MT * 32, BN = 128;
+    static constexpr int TH = BM / TW;
+    static constexpr int RPM = 32 / TW;
+    static constexpr int HH = (TH - 1) * STRIDE + KS, HW = (TW - 1) * STRIDE + KS;
+    static constexpr int RSH = ((HW * PSH + 127) / 128) * 128;     // row stride in halves (multiple of 256 B)
+    static constexpr int LDS_HALVES = HH * RSH;
+    static constexpr int NPIX = HH * HW;
+    static constexpr int NPASS = (NPIX + 63) / 64;                 // 64 pixel slots x 4 channel octets per pass
+    static constexpr int GPC = TAPS * 2;                           // (tap, 16-channel step) groups per chunk
+    static_assert(TW <= 32 && BM % TW == 0, "tile shape");
+    static_assert(LDS_HALVES * 2 <= 160 * 1024, "LDS budget");
+    static_assert(GPC % PF == 0 || PF > GPC, "ring depth");
+};
+
+__device__ __forceinline__ float silu16_f(float v) {
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
+}
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
+    constexpr int KC = C::KC, PSH = C::PSH, RSH = C::RSH, TAPS = C::TAPS, MT = C::MT, NPASS = C::NPASS, GPC = C::GPC;
+    constexpr int PF = C::PF < GPC ? C::PF : GPC;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[C::LDS_HALVES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int b = bx / p.tiles_y;
+    const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+    const int iy0 = oy0 * C::STRIDE - C::PAD, ix0 = ox0 * C::STRIDE - C::PAD;
+    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+
+    // ---- loader: thread -> (pixel slot pl of 64, channel octet q of 4) ----
+    const int q = tid & 3, pl = tid >> 2;
+    int soff[NPASS];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int hp = i * 64 + pl;
+        const int hy = hp / C::HW, hx = hp - hy * C::HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool ok = hp < C::NPIX && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+        soff[i] = ok ? ((b * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups)) : 0;
+        vmask |= ok ? (1u << i) : 0u;
+    }
+    float pre[NPASS][8];
+    f32x4 gsc[2], gsh[2];
+    bool cvalid;
+
+    auto issue_loads = [&](int chunk) {
+        const int s = chunk >= p.nchunk0;
+        const int cl = (s ? chunk - p.nchunk0 : chunk) * KC + q * 8;
+        const int cs = p.csrc[s];
+        cvalid = cl < cs;                       // channel counts are multiples of 8 (fp16) / 4 (fp32 conv_in: see host)
+        const int c0 = cvalid ? cl : 0;
+        if (p.src_f32) {
+            const float* __restrict__ base = static_cast<const float*>(p.src[s]) + c0;
+            const bool hi = c0 + 8 <= cs;       // fp32 sources may end on a 4-channel boundary
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
+                const float* a = base + (size_t)soff[i] * cs;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(a);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(hi ? a + 4 : a);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pre[i][e] = v0[e];
+                    pre[i][4 + e] = hi ? v1[e] : 0.f;
+                }
+            }
+        } else {
+            const _Float16* __restrict__ base = static_cast<const _Float16*>(p.src[s]) + c0;
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(base + (size_t)soff[i] * cs);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pre[i][e] = (float)v[e];
+            }
+        }
+        if (p.gn) {
+            const int cg = cvalid ? (s ? p.csrc[0] : 0) + cl : 0;
+            const float* gs = p.gscale + (size_t)b * p.ctot + cg;
+            const float* gh = p.gshift + (size_t)b * p.ctot + cg;
+            gsc[0] = *reinterpret_cast<const f32x4*>(gs);
+            gsc[1] = *reinterpret_cast<const f32x4*>(gs + 4);
+            gsh[0] = *reinterpret_cast<const f32x4*>(gh);
+            gsh[1] = *reinterpret_cast<const f32x4*>(gh + 4);
+        }
+    };
+
+    auto write_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int hp = i * 64 + pl;
+            const int hy = hp / C::HW, hx = hp - hy * C::HW;
+            const bool ok = cvalid && ((vmask >> i) & 1u);
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = pre[i][e];
+                if (p.gn) v = fmaf(v, gsc[e >> 2][e & 3], gsh[e >> 2][e & 3]);
+                if (p.silu) v = silu16_f(v);
+                o[e] = (_Float16)(ok ? v : 0.f);
+            }
+            if (hp < C::NPIX) *reinterpret_cast<f16x8*>(&lds[hy * RSH + hx * PSH + q * 8]) = o;
+        }
+    };
+
+    // ---- MFMA operand addressing ----
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_base = ((li >> C::LOGTW) * C::STRIDE) * RSH + ((li & (C::TW - 1)) * C::STRIDE) * PSH + lh * 8;
+    const int ntile = blockIdx.y * 4 + wn;
+    const bool nvalid = ntile * 32 < p.Cout;
+    // packed weights: [ntile][chunk][tap][j = 0..1][lane][8 halves] -> one group = 512 halves (1 KiB)
+    const _Float16* __restrict__ wp = p.w + ((size_t)(nvalid ? ntile : 0) * p.nchunks * TAPS) * 1024 + lane * 8;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    f16x8 ring[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) ring[j] = *reinterpret_cast<const f16x8*>(wp + j * 512);
+
+    issue_loads(0);
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        write_lds();
+        __syncthreads();
+        if (chunk + 1 < p.nchunks) issue_loads(chunk + 1);
+        if (nvalid) {
+            const _Float16* __restrict__ wc = wp + (size_t)chunk * (TAPS * 1024);
+#pragma unroll
+            for (int g = 0; g < GPC; ++g) {
+                const int tap = g >> 1, j = g & 1, ky = tap / C::KS, kx = tap % C::KS;
+                int ab = a_base;
+                asm volatile("" : "+v"(ab));                 // no cross-tap CSE of LDS reads (see conv_kernel.h)
+                __builtin_assume((ab & 7) == 0);
+                f16x8 a[MT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    a[t] = *reinterpret_cast<const f16x8*>(&lds[ab + (t * C::RPM * C::STRIDE + ky) * RSH + kx * PSH + j * 16]);
+                const f16x8 bq = ring[g % PF];
+                ring[g % PF] = *reinterpret_cast<const f16x8*>(wc + (size_t)(g + PF) * 512);   // wraps into the next chunk / tail pad
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t], bq, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    if (!nvalid) return;
+    const int n = ntile * 32 + li;
+    const bool nok = n < p.Cout;
+    float add = 0.f;
+    if (nok) {
+        add = p.bias ? p.bias[n] : 0.f;
+        if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
+    }
+    double s1 = 0.0, s2 = 0.0;
+    auto epilogue = [&](auto has_res, auto has_stats, auto out32) __attribute__((always_inline)) {
+        float rv[MT][16];
+        if constexpr (decltype(has_res)::value) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int oy = min(oy0 + (m >> C::LOGTW), p.Hout - 1), ox = min(ox0 + (m & (C::TW - 1)), p.Wout - 1);
+                    rv[t][r] = (float)p.residual[(((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + (nok ? n : 0)];
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int oy = oy0 + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
+                if (nok && oy < p.Hout && ox < p.Wout) {
+                    const size_t pix = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+                    float v = acc[t][r] + add;
+                    if constexpr (decltype(has_res)::value) v += rv[t][r];
+                    if constexpr (decltype(out32)::value) static_cast<float*>(p.out)[pix * p.out_ld + n] = v;
+                    else static_cast<_Float16*>(p.out)[pix * p.out_ld + n] = (_Float16)v;
+                    if constexpr (decltype(has_stats)::value) {
+                        const double d = (double)v;
+                        s1 += d;
+                        s2 = fma(d, d, s2);
+                    }
+                }
+            }
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (p.out_f32) {
+        if (p.residual) epilogue(T_{}, F_{}, T_{}); else epilogue(F_{}, F_{}, T_{});
+    } else if (p.residual) {
+        if (p.stats) epilogue(T_{}, T_{}, F_{}); else epilogue(T_{}, F_{}, F_{});
+    } else {
+        if (p.stats) epilogue(F_{}, T_{}, F_{}); else epilogue(F_{}, F_{}, F_{});
+    }
+    if (p.stats) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lh == 0 && nok) {
+            const int slot = ty * p.tiles_x + tx;
+            const int nslots = p.tiles_y * p.tiles_x;
+            double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + n) * 2;
+            o[0] = s1;
+            o[1] = s2;
+        }
+    }
+}
+
+template <class C>
+inline int conv16_launch(const Conv16Params& p, hipStream_t stream) {
+    dim3 grid(p.tiles_x * p.tiles_y * p.B, ceil_div(p.Cout, C::BN));
+    hipLaunchKernelGGL(conv16_kernel<C>, grid, dim3(256), 0, stream, p);
+    return check_launch();
+}
+
+int conv16_dispatch(int ks, int stride, int logtw, const Conv16Params& p, hipStream_t stream);
+
+}  // namespace cdx

@@ -19,7 +19,7 @@ def _stream() -> int:
 def _ptr(t, byte_off: int = 0):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.int32) and t.is_contiguous()
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.float16) and t.is_contiguous()
     return t.data_ptr() + byte_off
 
 
@@ -45,6 +45,68 @@ class PackedConv:
         if winograd and self.ksize == 3:
             self.w_wino = torch.from_numpy(_abi.pack_conv_weights_wino(w, c0, c1)).to(device)
         self.bias = None if bias is None else torch.as_tensor(np.asarray(bias, np.float32)).to(device)
+
+
+class PackedConv16:
+    """fp16 fragment image of one convolution's weights (bias stays float32)."""
+
+    def __init__(self, w_oihw, bias, c0: int, c1: int = 0, device="cuda"):
+        import numpy as np
+        w = np.asarray(w_oihw, dtype=np.float32)
+        self.cout, cin, self.ksize, _ = w.shape
+        assert cin == c0 + c1, (cin, c0, c1)
+        self.c0, self.c1 = c0, c1
+        self.w = torch.from_numpy(_abi.pack_conv_weights_f16(w, c0, c1)).to(device)
+        self.bias = None if bias is None else torch.as_tensor(np.asarray(bias, np.float32)).to(device)
+
+
+def conv16_args(pc: PackedConv16, src0, src1, out, *, stride=1, upsample=False, gn=None, silu=False,
+                temb=None, temb_off=0, temb_ld=0, residual=None, out_ld=None) -> _abi.ConvF16Args:
+    """fp16-storage convolution; src0 may be float32 (x_t buffer), out may be float32 (eps buffer)."""
+    B, hin, win, c0 = src0.shape
+    assert c0 == pc.c0 and (src1 is None) == (pc.c1 == 0)
+    hv, wv = (hin * 2, win * 2) if upsample else (hin, win)
+    hout, wout = (hv, wv) if stride == 1 else ((hv + 1) // 2, (wv + 1) // 2)
+    a = _abi.ConvF16Args()
+    a.src0, a.src1, a.c0, a.c1 = _ptr(src0), _ptr(src1), pc.c0, pc.c1
+    a.src_is_f32 = int(src0.dtype == torch.float32)
+    assert src1 is None or src1.dtype == src0.dtype
+    a.batch, a.hin, a.win, a.hout, a.wout = B, hin, win, hout, wout
+    a.cout, a.ksize, a.stride = pc.cout, pc.ksize, stride
+    a.flags = (_abi.CONV_UPSAMPLE2X if upsample else 0) | (_abi.CONV_GN if gn is not None else 0) | (_abi.CONV_SILU if silu else 0)
+    a.wpacked, a.bias = _ptr(pc.w), _ptr(pc.bias)
+    if gn is not None:
+        a.gn_scale, a.gn_shift = _ptr(gn[0]), _ptr(gn[1])
+    if temb is not None:
+        a.temb, a.temb_ld = _ptr(temb, 4 * temb_off), temb_ld or temb.shape[-1]
+    if residual is not None:
+        assert residual.dtype == torch.float16
+    a.residual = _ptr(residual)
+    a.out, a.out_is_f32, a.out_ld = _ptr(out), int(out.dtype == torch.float32), out_ld or out.shape[-1]
+    assert out.shape[0] == B and out.shape[1] == hout and out.shape[2] == wout and a.out_ld >= pc.cout
+    return a
+
+
+def conv16_stats_buffer(a: _abi.ConvF16Args, device) -> torch.Tensor:
+    import ctypes
+    slots = _abi.lib().cdx_conv_f16_stats_slots(ctypes.byref(a))
+    if slots <= 0:
+        raise _abi.CdxError("cdx_conv_f16_stats_slots: bad arguments")
+    buf = torch.zeros(a.batch, slots, a.cout, 2, dtype=torch.float64, device=device)
+    a.stats_out = buf.data_ptr()
+    return buf
+
+
+def conv16(pc: PackedConv16, src0, src1=None, *, out_dtype=torch.float16, want_stats=False, **kw):
+    B, hin, win, _ = src0.shape
+    up, stride = kw.get("upsample", False), kw.get("stride", 1)
+    hv, wv = (hin * 2, win * 2) if up else (hin, win)
+    hout, wout = (hv, wv) if stride == 1 else ((hv + 1) // 2, (wv + 1) // 2)
+    out = torch.zeros(B, hout, wout, kw.get("out_ld") or pc.cout, device=src0.device, dtype=out_dtype)
+    a = conv16_args(pc, src0, src1, out, **kw)
+    stats = conv16_stats_buffer(a, src0.device) if want_stats else None
+    _abi.call("conv_f16", a, None, 0, _stream())
+    return (out, stats) if want_stats else out
 
 
 def conv_args(pc: PackedConv, src0, src1, out, *, stride=1, upsample=False, gn=None, silu=False,
@@ -160,9 +222,10 @@ def gn_stats(src0, src1, gamma, beta, groups, eps=1e-5, want_moments=False):
 def attn_args(q, k, v, out, *, batch, nq, nk, heads, head_dim, q_ld, k_ld, v_ld, out_ld,
               q_off=0, k_off=0, v_off=0, scale=None) -> _abi.AttnArgs:
     a = _abi.AttnArgs()
-    a.q, a.q_ld = _ptr(q, 4 * q_off), q_ld
-    a.k, a.k_ld = _ptr(k, 4 * k_off), k_ld
-    a.v, a.v_ld = _ptr(v, 4 * v_off), v_ld
+    es = q.element_size()
+    a.q, a.q_ld = _ptr(q, es * q_off), q_ld
+    a.k, a.k_ld = _ptr(k, es * k_off), k_ld
+    a.v, a.v_ld = _ptr(v, es * v_off), v_ld
     a.batch, a.nq, a.nk, a.heads, a.head_dim = batch, nq, nk, heads, head_dim
     a.scale = scale if scale is not None else head_dim ** -0.5
     a.out, a.out_ld = _ptr(out), out_ld
@@ -170,13 +233,13 @@ def attn_args(q, k, v, out, *, batch, nq, nk, heads, head_dim, q_ld, k_ld, v_ld,
 
 
 def attention(q, k, v, heads: int, head_dim: int = 64):
-    """q [B,Nq,C], k/v [B,Nk,C] (C = heads*head_dim) -> softmax(q k^T / sqrt(d)) v  [B,Nq,C]."""
+    """q [B,Nq,C], k/v [B,Nk,C] (C = heads*head_dim) -> softmax(q k^T / sqrt(d)) v  [B,Nq,C]; float32 or float16 I/O."""
     B, nq, c = q.shape
     nk = k.shape[1]
-    out = torch.empty(B, nq, c, device=q.device)
+    out = torch.empty(B, nq, c, device=q.device, dtype=q.dtype)
     a = attn_args(q, k, v, out, batch=B, nq=nq, nk=nk, heads=heads, head_dim=head_dim,
                   q_ld=c, k_ld=k.shape[-1], v_ld=v.shape[-1], out_ld=c)
-    _abi.call("attn_f32", a, None, 0, _stream())
+    _abi.call("attn_f16" if q.dtype == torch.float16 else "attn_f32", a, None, 0, _stream())
     return out
 
 

@@ -37,6 +37,9 @@ class _Plan:
         self._ws_need = 0
         self._ws_calls = []      # indices of calls that use the shared workspace
         new = lambda *shape: self._hold(torch.empty(*shape, device=dev, dtype=torch.float32))  # noqa: E731
+        half = net.half                      # fp16 storage / fp16 MFMA for the UNet's activations and weights
+        adt = torch.float16 if half else torch.float32
+        newa = lambda *shape: self._hold(torch.empty(*shape, device=dev, dtype=adt))  # noqa: E731  (activations)
 
         self.xin_ld = _pad4(g.cin_total)
         self.xin = self._hold(torch.zeros(B, H, H, self.xin_ld, device=dev))     # x_t | cond | 0
@@ -63,10 +66,11 @@ class _Plan:
             gamma, beta = net.dev[name + ".weight"], net.dev[name + ".bias"]
             st0 = stats_of.get(src0.data_ptr())
             st1 = None if src1 is None else stats_of.get(src1.data_ptr())
-            if net.fuse_gn_stats and st0 is not None and (src1 is None or st1 is not None):
+            if (net.fuse_gn_stats or half) and st0 is not None and (src1 is None or st1 is not None):
                 hw = src0.shape[1] * src0.shape[2]
                 self._add("gn_finalize_f32", ops.gn_finalize_args(st0, st1, hw, gamma, beta, cfg["groups"], sc, sh))
             else:
+                assert not half, "fp16 tensors always carry fused GroupNorm sums"
                 self._add("gn_stats_f32", ops.gn_stats_args(src0, src1, gamma, beta, cfg["groups"], sc, sh), ws=True)
             return sc, sh
 
@@ -78,7 +82,13 @@ class _Plan:
             out = kw.pop("out", None)
             normed_later = kw.pop("normed_later", False)     # a GroupNorm will read this output
             if out is None:
-                out = new(Bn, (hv + s - 1) // s, (wv + s - 1) // s, pc.cout)
+                out = newa(Bn, (hv + s - 1) // s, (wv + s - 1) // s, pc.cout)
+            if half:
+                a = ops.conv16_args(pc, src0, src1, out, **kw)
+                if normed_later:
+                    stats_of[out.data_ptr()] = self._hold(ops.conv16_stats_buffer(a, dev))
+                self._add("conv_f16", a)
+                return out
             a = ops.conv_args(pc, src0, src1, out, **kw)
             if normed_later and net.fuse_gn_stats:
                 stats_of[out.data_ptr()] = self._hold(ops.conv_stats_buffer(a, dev))
@@ -100,8 +110,8 @@ class _Plan:
             n = blk.name
             Bn, hh, ww, c = x.shape
             qkv = conv(n + ".qkv", x, gn=gn(n + ".norm", x))
-            o = new(Bn, hh, ww, c)
-            self._add("attn_f32", ops.attn_args(qkv, qkv, qkv, o, batch=Bn, nq=hh * ww, nk=hh * ww,
+            o = newa(Bn, hh, ww, c)
+            self._add("attn_f16" if half else "attn_f32", ops.attn_args(qkv, qkv, qkv, o, batch=Bn, nq=hh * ww, nk=hh * ww,
                                                  heads=c // cfg["head_dim"], head_dim=cfg["head_dim"],
                                                  q_ld=3 * c, k_ld=3 * c, v_ld=3 * c, out_ld=c, k_off=c, v_off=2 * c))
             return conv(n + ".proj", o, residual=x, normed_later=True)
@@ -112,8 +122,8 @@ class _Plan:
             q = conv(n + ".q", x, gn=gn(n + ".norm", x))
             kv = conv(n + ".kv", self.ctx)                       # [B, lh, lw, 2c]
             L = self.ctx.shape[1] * self.ctx.shape[2]
-            o = new(Bn, hh, ww, c)
-            self._add("attn_f32", ops.attn_args(q, kv, kv, o, batch=Bn, nq=hh * ww, nk=L,
+            o = newa(Bn, hh, ww, c)
+            self._add("attn_f16" if half else "attn_f32", ops.attn_args(q, kv, kv, o, batch=Bn, nq=hh * ww, nk=L,
                                                  heads=c // cfg["head_dim"], head_dim=cfg["head_dim"],
                                                  q_ld=c, k_ld=2 * c, v_ld=2 * c, out_ld=c, v_off=c))
             return conv(n + ".proj", o, residual=x, normed_later=True)
@@ -134,7 +144,7 @@ class _Plan:
         if cross:
             L, D = (H // 16) ** 2, cfg["context_dim"]
             lw = 32 if L % 32 == 0 else L
-            self.ctx = self._hold(torch.zeros(B, L // lw, lw, D, device=dev))
+            self.ctx = self._hold(torch.zeros(B, L // lw, lw, D, device=dev, dtype=adt))
 
         h = conv("conv_in", self.xin, normed_later=True)
         skips = [h]
@@ -186,6 +196,7 @@ class UNet:
                  fuse_gn_stats: bool = True):
         _abi.lib()   # fail loudly now if the extension is missing
         self.fuse_gn_stats = fuse_gn_stats   # False: every GroupNorm re-reads its input (cdx_gn_stats_f32)
+        self.half = validate_unet_config(cfg)["dtype"] == "fp16"
         if not torch.cuda.is_available():
             raise RuntimeError("UNet (HIP backend) needs a GPU; there is no CPU fallback in the product path")
         self.cfg = validate_unet_config(cfg)
@@ -219,14 +230,14 @@ class UNet:
                 for b in res_blocks:    # up-path ResBlocks read (x, skip) as two sources
                     if b.skip_ch and base in (b.name + ".conv1", b.name + ".skip"):
                         c0, c1 = b.cin - b.skip_ch, b.skip_ch
-                self.convs[base] = ops.PackedConv(w, bias, c0, c1, self.device)
+                self.convs[base] = (ops.PackedConv16 if self.half else ops.PackedConv)(w, bias, c0, c1, self.device)
             elif ".norm" in name or name.startswith("temb."):
                 self.dev[name] = up(P[name])
         for b in g.down + g.mid + g.up:
             if b.kind == "xattn":   # kv projection of the context tokens runs as a 1x1 convolution
                 w = P[b.name + ".kv.weight"]
-                self.convs[b.name + ".kv"] = ops.PackedConv(w[:, :, None, None], P[b.name + ".kv.bias"],
-                                                            w.shape[1], 0, self.device)
+                self.convs[b.name + ".kv"] = (ops.PackedConv16 if self.half else ops.PackedConv)(
+                    w[:, :, None, None], P[b.name + ".kv.bias"], w.shape[1], 0, self.device)
         # all ResBlock temb projections as one [sum(cout), temb_dim] linear
         self.tproj_off, off = {}, 0
         for b in res_blocks:
@@ -266,4 +277,4 @@ def load_cond(p: _Plan, cfg: dict, cond: torch.Tensor) -> None:
         assert c.shape[1] == cfg["cond_channels"], c.shape
         ops.cond_embed(c, p.xin, cfg["in_channels"])
     else:
-        p.ctx.view(p.batch, -1, cfg["context_dim"]).copy_(cond.to(dev, torch.float32))
+        p.ctx.view(p.batch, -1, cfg["context_dim"]).copy_(cond.to(dev, torch.float32))   # (casts to fp16 when the plan is)

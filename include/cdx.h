@@ -122,6 +122,42 @@ size_t cdx_conv_wino_packed_floats(int32_t c0, int32_t c1, int32_t cout);
 int cdx_conv_pack_weights_wino_f32(const float* w_oihw, int32_t c0, int32_t c1, int32_t cout, float* packed);
 
 /* ------------------------------------------------------------------------------------------
+ * fp16-storage variants (BASELINE.json configs[4]; SURVEY.md 8a "_f16 variants"): activations and weights in IEEE
+ * binary16, products on v_mfma_f32_32x32x16_f16, float32 accumulation; GroupNorm scale/shift, bias, temb and the
+ * GroupNorm partial sums stay float32 / float64.  Sources may be float32 (the sampler's x_t buffer) and the output
+ * float32 (the eps buffer).  Channel counts: multiples of 8 for fp16 tensors, of 4 for fp32 sources.
+ * ------------------------------------------------------------------------------------------ */
+typedef uint16_t cdx_half; /* IEEE binary16 bit pattern */
+
+typedef struct cdx_conv_f16_args {
+    const void* src0;      /* [batch, hin, win, c0] fp16 (or fp32 if src_is_f32) */
+    const void* src1;      /* second concat source or NULL */
+    int32_t c0, c1;
+    int32_t src_is_f32;
+    int32_t batch, hin, win, hout, wout, cout, ksize, stride, flags; /* as cdx_conv_args */
+    const cdx_half* wpacked; /* cdx_conv_pack_weights_f16 */
+    const float* bias;
+    const float* gn_scale;
+    const float* gn_shift;
+    const float* temb;
+    int32_t temb_ld;
+    const cdx_half* residual; /* [batch, hout, wout, cout] or NULL */
+    void* out;                /* fp16 (or fp32 if out_is_f32) [batch, hout, wout, out_ld] */
+    int32_t out_is_f32;
+    int32_t out_ld;
+    double* stats_out;        /* NULL or [batch, cdx_conv_f16_stats_slots(a), cout, 2] */
+} cdx_conv_f16_args;
+
+int cdx_conv_f16(const cdx_conv_f16_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_conv_f16_workspace(const cdx_conv_f16_args* a);
+int32_t cdx_conv_f16_stats_slots(const cdx_conv_f16_args* a);
+/* HOST: fp16 fragment image of float32 OIHW weights (round-to-nearest-even):
+ *   [ntile][chunk][tap][j = 0..1][lane = 0..63][e = 0..7] = W[n = 32*ntile + (lane&31)][c = chunk_base + 16*j + 8*(lane>>5) + e][tap]
+ * + 16 KiB zero pad.  Sizes are in halves. */
+size_t cdx_conv_f16_packed_halves(int32_t c0, int32_t c1, int32_t cout, int32_t ksize);
+int cdx_conv_pack_weights_f16(const float* w_oihw, int32_t c0, int32_t c1, int32_t cout, int32_t ksize, cdx_half* packed);
+
+/* ------------------------------------------------------------------------------------------
  * U2: GroupNorm statistics of cat[src0, src1] -> per-(batch, channel) scale / shift
  *   scale[b][c] = rstd[b][g(c)] * gamma[c];  shift[b][c] = beta[c] - mean[b][g(c)] * scale[b][c]
  * (F.group_norm's own two-step form).  Sums are carried in float64, fixed order (deterministic).
@@ -178,6 +214,9 @@ typedef struct cdx_attn_args {
 
 int cdx_attn_f32(const cdx_attn_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
 size_t cdx_attn_f32_workspace(const cdx_attn_args* a);
+/* attention core with fp16 q/k/v/out (float32 softmax and accumulation); same arguments as cdx_attn_f32 */
+int cdx_attn_f16(const cdx_attn_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_attn_f16_workspace(const cdx_attn_args* a);
 
 /* ------------------------------------------------------------------------------------------
  * U1: small-M linear  out[m][n] = sum_k act(x[m][k]) * w[n][k] + bias[n]   (F.linear)

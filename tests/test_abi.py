@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_struct_layouts_match_c(tmp_path):
     """Compile a C program that prints sizeof/offsetof for every args struct and compare with ctypes."""
     A = cdx._abi
-    structs = {"cdx_conv_args": A.ConvArgs, "cdx_gn_stats_args": A.GnStatsArgs, "cdx_gn_finalize_args": A.GnFinalizeArgs, "cdx_attn_args": A.AttnArgs,
+    structs = {"cdx_conv_args": A.ConvArgs, "cdx_conv_f16_args": A.ConvF16Args, "cdx_gn_stats_args": A.GnStatsArgs, "cdx_gn_finalize_args": A.GnFinalizeArgs, "cdx_attn_args": A.AttnArgs,
                "cdx_linear_args": A.LinearArgs, "cdx_timestep_embedding_args": A.TimestepEmbeddingArgs,
                "cdx_diffusion_update_args": A.DiffusionUpdateArgs, "cdx_gauss_fill_args": A.GaussFillArgs,
                "cdx_cond_embed_args": A.CondEmbedArgs, "cdx_export_image_args": A.ExportImageArgs, "cdx_tile_blend_args": A.TileBlendArgs}
