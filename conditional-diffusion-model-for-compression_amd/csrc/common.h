@@ -34,6 +34,22 @@ __host__ __device__ inline uint64_t stream_key(uint64_t seed, uint64_t a, uint64
     return mix64(k ^ (b + kGold));
 }
 
+// 4x4 transpose across a lane quad (lanes 4k..4k+3), in registers: on entry lane q holds x[i] = value(row i, col q);
+// on exit lane q holds x[j] = value(row q, col j).  Two butterfly stages (xor 1, xor 2 -> DPP quad permutes).
+// Used by the convolution epilogues: accumulator layout (lane = channel, register = pixel) -> (lane = pixel, 4
+// consecutive channels in registers), so outputs / residuals move as 8- or 16-byte accesses instead of 2- or 4-byte.
+__device__ __forceinline__ void quad_transpose(float (&x)[4], int q) {
+    const bool odd = q & 1;
+    const float r0 = __shfl_xor(odd ? x[0] : x[1], 1), r1 = __shfl_xor(odd ? x[2] : x[3], 1);
+    const float a0 = odd ? r0 : x[0], a1 = odd ? x[1] : r0, a2 = odd ? r1 : x[2], a3 = odd ? x[3] : r1;
+    const bool hi = q & 2;
+    const float u0 = __shfl_xor(hi ? a0 : a2, 2), u1 = __shfl_xor(hi ? a1 : a3, 2);
+    x[0] = hi ? u0 : a0;
+    x[1] = hi ? u1 : a1;
+    x[2] = hi ? a2 : u0;
+    x[3] = hi ? a3 : u1;
+}
+
 }  // namespace cdx
 
 #define CDX_REQUIRE(cond) \

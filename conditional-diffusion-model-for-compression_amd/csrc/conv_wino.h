@@ -551,6 +551,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_persist_kernel(const ConvPar
         }
     };
 
+    if constexpr (C::OPT & 128) {
+        // OPT 128 (experiment): de-phase the 256 persistent workgroups -- without it every CU stores its tile and
+        // fetches the next residual tile in the same microsecond.  8 phases spread over ~one chunk time.
+        const int ph = (blockIdx.x * 5) & 7;
+        for (int i = 0; i < ph * 3; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     // ---- stream prologue: first tile's chunk 0 staged, chunk 1 (or the next tile's chunk 0) in flight ----
     int item = blockIdx.x;           // grid.x <= total
     issue_next();
