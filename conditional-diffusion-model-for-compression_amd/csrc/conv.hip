@@ -146,6 +146,8 @@ int validate(const cdx_conv_args* a) {
     CDX_REQUIRE(aligned16(a->src0) && aligned16(a->src1) && aligned16(a->wpacked));
     if (a->flags & CDX_CONV_GN) CDX_REQUIRE(a->gn_scale && a->gn_shift && aligned16(a->gn_scale) && aligned16(a->gn_shift));
     if (a->temb) CDX_REQUIRE(a->temb_ld >= a->cout);
+    if (a->stats_out) CDX_REQUIRE((a->cout % 4) == 0 && (a->out_ld % 4) == 0);   // sums are produced by the packed epilogue
+    if (a->residual && (a->cout % 4) == 0) CDX_REQUIRE(aligned16(a->residual));
     // 32-bit pixel indexing inside the kernel
     CDX_REQUIRE((int64_t)a->batch * a->hin * a->win < (1ll << 31) && (int64_t)a->batch * a->hout * a->wout < (1ll << 31));
     return CDX_OK;

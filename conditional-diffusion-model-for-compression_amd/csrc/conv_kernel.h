@@ -283,23 +283,19 @@ __global__ __launch_bounds__(256, (C::OPT & OPT_OCC2) ? 2 : 3) void conv_kernel(
         add = p.bias ? p.bias[n] : 0.f;
         if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
     }
-    double s1 = 0.0, s2 = 0.0;      // per-channel sum / sum of squares of the stored values (GroupNorm of `out`)
-    // The residual / stats tests are hoisted out of the unrolled loops on purpose: a per-element "load or not"
-    // makes hipcc branch around every load and wait vmcnt(0) each time (64 serial HBM round trips).
-    auto epilogue = [&](auto has_res, auto has_stats) __attribute__((always_inline)) {
-        float rv[MT][16];
-        if constexpr (decltype(has_res)::value) {
+    // Packed epilogue: 4x4 blocks (4 consecutive pixels x the lane quad's 4 channels) are transposed across lane
+    // quads in registers (quad_transpose), so every lane stores / loads 4 consecutive channels of ONE pixel as 16 bytes:
+    // 4x fewer, 4x wider memory instructions than the accumulator layout allows.  GroupNorm sums (float64, of the
+    // stored values) are reduced in that layout.  The residual / stats tests are hoisted out of the unrolled loops on
+    // purpose: a per-element "load or not" makes hipcc branch around every load and wait vmcnt(0) each time.
+    const int q4 = li & 3;
+    const int cq = ntile * 32 + (li & ~3);                    // first of this quad's 4 channels
+    const bool quad_ok = cq < p.Cout;
+    const bool vec_ok = (p.out_ld & 3) == 0 && cq + 4 <= p.out_ld && (p.Cout & 3) == 0;
+    if (!vec_ok) {
+        // scalar fallback (cout not a multiple of 4, e.g. the 3-channel eps output with out_ld 3)
 #pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (wm * MT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int oy = min(oy0 + (m >> C::LOGTW), p.Hout - 1), ox = min(ox0 + (m & (C::TW - 1)), p.Wout - 1);
-                    rv[t][r] = p.residual[(((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + (nok ? n : 0)];
-                }
-        }
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (wm * MT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -307,12 +303,47 @@ __global__ __launch_bounds__(256, (C::OPT & OPT_OCC2) ? 2 : 3) void conv_kernel(
                 if (nok && oy < p.Hout && ox < p.Wout) {
                     const size_t pix = ((size_t)b * p.Hout + oy) * p.Wout + ox;
                     float v = acc[t][r] + add;
-                    if constexpr (decltype(has_res)::value) v += rv[t][r];
+                    if (p.residual) v += p.residual[pix * p.Cout + n];
                     p.out[pix * p.out_ld + n] = v;
+                }
+            }
+        return;      // (GroupNorm sums are only requested for multiple-of-4 channel counts)
+    }
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    auto epilogue = [&](auto has_res, auto has_stats) __attribute__((always_inline)) {
+        f32x4 rv[MT][4];
+        if constexpr (decltype(has_res)::value) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int m = (wm * MT + t) * 32 + 8 * k + q4 + 4 * lh;
+                    const int oy = min(oy0 + (m >> C::LOGTW), p.Hout - 1), ox = min(ox0 + (m & (C::TW - 1)), p.Wout - 1);
+                    rv[t][k] = *reinterpret_cast<const f32x4*>(p.residual + (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + (quad_ok ? cq : 0));
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float x[4] = {acc[t][4 * k] + add, acc[t][4 * k + 1] + add, acc[t][4 * k + 2] + add, acc[t][4 * k + 3] + add};
+                quad_transpose(x, q4);                        // now: pixel 8k + q4 (+4 lh) of tile t, channels cq..cq+3
+                const int m = (wm * MT + t) * 32 + 8 * k + q4 + 4 * lh;
+                const int oy = oy0 + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
+                if (quad_ok && oy < p.Hout && ox < p.Wout) {
+                    const size_t pix = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+                    if constexpr (decltype(has_res)::value) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) x[c] += rv[t][k][c];
+                    }
+                    *reinterpret_cast<f32x4*>(p.out + pix * p.out_ld + cq) = f32x4{x[0], x[1], x[2], x[3]};
                     if constexpr (decltype(has_stats)::value) {
-                        const double d = (double)v;
-                        s1 += d;
-                        s2 = fma(d, d, s2);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const double d = (double)x[c];
+                            s1[c] += d;
+                            s2[c] = fma(d, d, s2[c]);
+                        }
                     }
                 }
             }
@@ -323,14 +354,24 @@ __global__ __launch_bounds__(256, (C::OPT & OPT_OCC2) ? 2 : 3) void conv_kernel(
     if (p.residual) { if (p.stats) epilogue(T_{}, T_{}); else epilogue(T_{}, F_{}); }
     else { if (p.stats) epilogue(F_{}, T_{}); else epilogue(F_{}, F_{}); }
     if (p.stats) {      // wave-uniform
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (lh == 0 && nok) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {      // the quad's 4 lanes and the two lane halves hold different pixels
+            s1[c] += __shfl_xor(s1[c], 1);
+            s2[c] += __shfl_xor(s2[c], 1);
+            s1[c] += __shfl_xor(s1[c], 2);
+            s2[c] += __shfl_xor(s2[c], 2);
+            s1[c] += __shfl_xor(s1[c], 32);
+            s2[c] += __shfl_xor(s2[c], 32);
+        }
+        if (lh == 0 && q4 == 0 && quad_ok) {
             const int slot = (ty * p.tiles_x + tx) * C::WM + wm;
             const int nslots = p.tiles_y * p.tiles_x * C::WM;
-            double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + n) * 2;
-            o[0] = s1;
-            o[1] = s2;
+            double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + cq) * 2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                o[2 * c] = s1[c];
+                o[2 * c + 1] = s2[c];
+            }
         }
     }
 }

@@ -296,45 +296,77 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p) {
     // above the main loop and spills them (and accumulators) to scratch.
     int eoy0 = oy0, eox0 = ox0, elh = lh;
     asm volatile("" : "+s"(eoy0), "+s"(eox0), "+v"(elh));
-    double s1 = 0.0, s2 = 0.0;
+    // Packed stores: for each of the 4 output positions (a, bb) of a tile, blocks of 4 tile-registers are transposed
+    // across lane quads (quad_transpose), so a lane stores 4 consecutive channels of ONE pixel as 16 bytes -- 16 stores
+    // per lane instead of 64.  GroupNorm sums are reduced in that layout.
+    const int q4 = li & 3;
+    const int cq = ntile * 32 + (li & ~3);
+    const bool quad_ok = cq < p.Cout;
+    const bool vec_ok = (p.out_ld & 3) == 0 && cq + 4 <= p.out_ld;      // else: scalar stores (e.g. out_ld == cout == 3)
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        // this register's tile: MFMA row (r&3) + 8*(r>>2) + 4*lh  ->  (tile row, tile col)
-        const int tile = (r & 3) + 8 * (r >> 2) + 4 * elh;
-        const int oy = eoy0 + 2 * (tile >> 4), ox = eox0 + 2 * (tile & 15);
-        float t[2][4];
+    for (int k = 0; k < 4; ++k) {
+        float y[4][4];      // [register 4k+i][output position a*2+bb] for this lane's channel
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t[0][j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
-            t[1][j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * k + i;
+            float t[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
+                t[1][j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                y[i][a * 2 + 0] = t[a][0] + t[a][1] + t[a][2];
+                y[i][a * 2 + 1] = t[a][1] - t[a][2] - t[a][3];
+            }
         }
+        const int tile = 8 * k + q4 + 4 * elh;                       // the tile this lane owns after the transposes
+        const int oy = eoy0 + 2 * (tile >> 4), ox = eox0 + 2 * (tile & 15);
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const float y[2] = {t[a][0] + t[a][1] + t[a][2], t[a][1] - t[a][2] - t[a][3]};
+        for (int pos = 0; pos < 4; ++pos) {
+            float x[4] = {y[0][pos], y[1][pos], y[2][pos], y[3][pos]};
+            quad_transpose(x, q4);                                    // x[c] = channel cq + c at pixel (oy + pos/2, ox + pos%2)
+            const int py = oy + (pos >> 1), px = ox + (pos & 1);
+            if (quad_ok && py < p.Hout && px < p.Wout) {
+                const size_t pix = ((size_t)b * p.Hout + py) * p.Wout + px;
+                if (vec_ok) *reinterpret_cast<f32x4*>(p.out + pix * p.out_ld + cq) = f32x4{x[0], x[1], x[2], x[3]};
+                else
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                if (nok && oy + a < p.Hout && ox + bb < p.Wout) {
-                    const size_t pix = ((size_t)b * p.Hout + oy + a) * p.Wout + ox + bb;
-                    const float v = y[bb];
-                    p.out[pix * p.out_ld + n] = v;
-                    if (p.stats) {
-                        const double dv = (double)v;
-                        s1 += dv;
-                        s2 = fma(dv, dv, s2);
+                    for (int c = 0; c < 4; ++c)
+                        if (cq + c < p.Cout) p.out[pix * p.out_ld + cq + c] = x[c];
+                if (p.stats) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double dv = (double)x[c];
+                        s1[c] += dv;
+                        s2[c] = fma(dv, dv, s2[c]);
                     }
                 }
             }
         }
     }
     if (p.stats) {
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (lh == 0 && nok) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            s1[c] += __shfl_xor(s1[c], 1);
+            s2[c] += __shfl_xor(s2[c], 1);
+            s1[c] += __shfl_xor(s1[c], 2);
+            s2[c] += __shfl_xor(s2[c], 2);
+            s1[c] += __shfl_xor(s1[c], 32);
+            s2[c] += __shfl_xor(s2[c], 32);
+        }
+        if (lh == 0 && q4 == 0 && quad_ok) {
             const int slot = ty * p.tiles_x + tx;
             const int nslots = p.tiles_y * p.tiles_x;
-            double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + n) * 2;
-            o[0] = s1;
-            o[1] = s2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (cq + c < p.Cout) {
+                    double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + cq + c) * 2;
+                    o[0] = s1[c];
+                    o[1] = s2[c];
+                }
         }
     }
 }
