@@ -20,12 +20,13 @@ from .unet import UNet, load_cond
 
 class Sampler:
     def __init__(self, unet: UNet, schedule: dict | None = None, method: str = "ddim", *,
-                 eta: float = 0.0, clip_x0: bool = True):
+                 eta: float = 0.0, clip_x0: bool = True, use_graph: bool = False):
         if method not in ("ddim", "ddpm"):
             raise ValueError(f"method must be 'ddim' or 'ddpm', got {method!r}")
         if eta != 0.0:
             raise ValueError("only eta = 0 (deterministic DDIM) is defined")
         self.unet, self.method, self.clip_x0 = unet, method, clip_x0
+        self.use_graph = use_graph       # replay the UNet forward as one hipGraph launch (host-bound workloads)
         self.schedule = make_schedule(schedule)
 
     @torch.no_grad()
@@ -39,6 +40,8 @@ class Sampler:
         net, cfg = self.unet, self.unet.cfg
         B, C = cond.shape[0], cfg["in_channels"]
         p = net.plan(B)
+        if self.use_graph:
+            p.capture()
         coefs = step_coefficients(self.schedule, steps, self.method)
         st = torch.cuda.current_stream().cuda_stream
         load_cond(p, cfg, cond)

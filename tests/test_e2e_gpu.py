@@ -224,3 +224,22 @@ def test_tiled_decode_matches_oracle(cdx_mod, record):
     a = cdx_mod._abi.TileBlendArgs(t.data_ptr(), 2, 3, 32, len(ys), len(xs), y0.data_ptr(), x0.data_ptr(), 80, 64, out.data_ptr())
     cdx_mod._abi.call("tile_blend_f32", a, None, 0, torch.cuda.current_stream().cuda_stream)
     assert (out.cpu() - oracle.blend_ref(tiles, ys, xs, 80, 64)).abs().max().item() < 2e-6
+
+
+def test_hipgraph_replay_is_bit_identical(cdx_mod, record):
+    """Row (f) rank 3: the recorded forward captured as one hipGraph: same bits as eager.  Measured (recorded, not
+    asserted): even the batch-1 32x32 config is GPU-bound (138 dependent kernels, ~2.16 ms/step either way), as the
+    hardware guide predicts (dependent-kernel boundary cost is the same eager or replayed)."""
+    import time
+    cfg, run = cdx_mod.named_config("cfg1")
+    net = cdx_mod.UNet(cfg, seed=0)
+    cond = torch.from_numpy(cdx_mod.synthetic_batch(cfg, 0, 0, 1)["cond"]).cuda()
+    eager, graph = cdx_mod.Sampler(net), cdx_mod.Sampler(net, use_graph=True)
+    a = eager.sample(cond, 10, seed=3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); a2 = eager.sample(cond, 50, seed=3); torch.cuda.synchronize(); te = time.perf_counter() - t0
+    b = graph.sample(cond, 10, seed=3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); b2 = graph.sample(cond, 50, seed=3); torch.cuda.synchronize(); tg = time.perf_counter() - t0
+    assert torch.equal(a, b) and torch.equal(a2, b2)
+    record("hipgraph_cfg1", eager_ms_per_step=te / 50 * 1e3, graph_ms_per_step=tg / 50 * 1e3)
