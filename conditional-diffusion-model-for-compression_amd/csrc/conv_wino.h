@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p) {
         if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
         // NOTE: the residual test is hoisted out of the unrolled loops on purpose -- a per-element "load or not"
         // makes hipcc branch around every load and wait vmcnt(0) each time (64 serial HBM round trips).
-        if (p.residual) {
+        if (p.residual && !(C::OPT & 256)) {   // OPT 256 (ablation): no residual loads
             float rv[64];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -243,11 +243,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p) {
         for (int g = 0; g < GPC; ++g) {
             const int hh = g >> 1;
             if ((g & 1) == 0 && hh + 1 < 8) load_half(cur, hh + 1, dh[(hh + 1) & 1]);      // prefetch the next half
-            if (g + 1 < GPC) transform(dh[((g + 1) >> 1) & 1], (g + 1) & 1, vv[(g + 1) & 1]);   // next group's operands
+            if (g + 1 < GPC) {   // next group's operands (OPT 8, ablation: raw patch values, no transform adds)
+                if constexpr (C::OPT & 8) {
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) vv[(g + 1) & 1][x] = dh[((g + 1) >> 1) & 1][x][(g + 1) & 1];
+                } else transform(dh[((g + 1) >> 1) & 1], (g + 1) & 1, vv[(g + 1) & 1]);
+            }
             // Second half of the chunk: stage the NEXT chunk into the other buffer, one halo pass per MFMA group
             // (its ~30 VALU + one ds_write_b128 hide under the group's 16 MFMAs), then start the loads of the
             // chunk after that.
-            if (more) {
+            if (more && !(C::OPT & 4)) {   // OPT 4 (ablation): no staging of later chunks
                 constexpr int G0 = GPC - NPASS - 1;          // first staging group
                 if (g >= G0 && g < G0 + NPASS) write_pass(nxt, g - G0);
                 if (g == G0 + NPASS && chunk + 2 < p.nchunks) issue_loads(chunk + 2);
@@ -256,7 +261,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p) {
             for (int xq = 0; xq < 4; ++xq) {      // xi = 4*xq + j: row xq of V, column j
                 const int f = g * 4 + xq;
                 const f32x4 bq = ring[f % RF];
-                ring[f % RF] = *reinterpret_cast<const f32x4*>(wc + (f + RF) * 256 + lane4);
+                if constexpr (!(C::OPT & 1))   // OPT 1 (ablation): never refill the weight ring
+                    ring[f % RF] = *reinterpret_cast<const f32x4*>(wc + (f + RF) * 256 + lane4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[xq * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[g & 1][xq * 4 + j], bq[j], acc[xq * 4 + j], 0, 0, 0);

@@ -10,6 +10,11 @@ int conv_dispatch_wino(int variant, const ConvParams& p, hipStream_t stream) {
         case 35: return conv_wino_persist_launch<WinoCfg<2, 0>>(p, stream);
         case 37: return conv_wino_persist_launch<WinoCfg<2, 128>>(p, stream);
         case 36: return conv_wino_persist_launch<WinoCfg<4, 0>>(p, stream);
+        case 38: return conv_wino_launch<WinoCfg<2, 16>>(p, stream);   // ablation: no epilogue
+        case 39: return conv_wino_launch<WinoCfg<2, 285>>(p, stream);  // ablation: MFMA stream only (1|4|8|16|256)
+        case 40: return conv_wino_launch<WinoCfg<2, 13>>(p, stream);   // ablation: loop stripped (1|4|8), prologue + epilogue kept
+        case 41: return conv_wino_launch<WinoCfg<2, 256>>(p, stream);  // ablation: no residual loads
+        case 42: return conv_wino_launch<WinoCfg<2, 272>>(p, stream);  // ablation: no residual loads, no epilogue
         case 34: return conv_wino_launch<WinoCfg<2, 64>>(p, stream);
         default: return CDX_ENOTSUP;
     }
