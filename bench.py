@@ -105,7 +105,7 @@ def measure_dominant_kernel(plan, torch, reps=3):
     executed = achieved / 2.25 if wino else achieved
     roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": None,
-            "kernel": ("conv_wino_kernel<WinoCfg> (Winograd F(2x2,3x3), ksize %d stride %d log2TW %d tile %s)" if wino else
+            "kernel": ("conv_wino8_kernel<WinoCfg<2,0>> (Winograd F(2x2,3x3), ksize %d stride %d log2TW %d tile %s)" if wino else
                        "conv16_kernel<Conv16Cfg> (fp16 MFMA, ksize %d stride %d log2TW %d tile %s)" if half else
                        "conv_kernel<ConvCfg<ksize %d, stride %d, log2TW %d, tile %s>>") % dom,
             "flop_accounting": "achieved = ALGORITHMIC direct-convolution FLOPs (2*Cin*Cout*9*H*W*B) / measured time"

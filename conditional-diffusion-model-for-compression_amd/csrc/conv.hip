@@ -97,7 +97,7 @@ Tile tile_of(int wcfg) {
         case WCFG_2x2x1: return {wcfg, 64, 64, 2};
         case WCFG_S32: return {wcfg, 32, 32, 1};
         case WCFG_S64: return {wcfg, 64, 32, 1};
-        case WCFG_WINO: return {wcfg, 128, 128, 1};
+        case WCFG_WINO: return {wcfg, 128, 128, 2};   // (wm = 2: the 8-wave kernel writes two GroupNorm slots per tile)
         default: return {-1, 0, 0, 0};
     }
 }
@@ -177,7 +177,7 @@ extern "C" int cdx_conv_f32(const cdx_conv_args* a, void* ws, size_t ws_bytes, c
 extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, size_t, cdx_stream_t stream) {
     int rc = validate(a);
     if (rc) return rc;
-    const bool experimental = tile >= 16;   // conv_exp.hip: tuning variants of the 128 x 128 tile
+    const bool experimental = tile >= 16;   // conv_exp.hip (16..30) / conv_wino.hip (31..): tuning variants
     Tile t = tile < 0 ? select_tile(a) : experimental ? Tile{tile, 128, 128, 1} : tile_of(tile);
     if (t.wcfg < 0 || (!experimental && !tile_allowed(a, t.wcfg))) return CDX_ENOTSUP;
     if (experimental && !(a->ksize == 3 && a->stride == 1)) return CDX_ENOTSUP;
@@ -205,7 +205,7 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
 
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (t.wcfg == WCFG_WINO || (experimental && tile >= 32)) {
+    if (t.wcfg == WCFG_WINO || (experimental && tile >= 31)) {
         if (!wino_ok(a)) return CDX_ENOTSUP;
         p.w = a->wpacked_wino;
         return conv_dispatch_wino(experimental ? tile : 0, p, st);

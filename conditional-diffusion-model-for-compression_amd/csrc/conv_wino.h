@@ -726,6 +726,348 @@ inline int conv_wino_persist_launch(const ConvParams& p, hipStream_t stream) {
     return check_launch();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 8-wave form: two waves per SIMD.  Wave (wn = N quarter, wh = half) owns V rows {2*wh, 2*wh + 1} of every tile, i.e. 8
+// of the 16 transform-domain products: 128 accumulator registers, half of the input-transform adds, 12 of the 16 patch
+// pixels, its own half of the weight fragments.  Both waves of a SIMD run the same program out of phase, so one's
+// VALU / LDS / staging work issues under the other's MFMAs (the overlap a lone 512-register wave cannot have).
+// A^T M A is linear in M: each half produces a partial 2x2 output per tile and the halves are summed once per tile
+// through LDS (registers 0..7 of a lane are finished by half 0, 8..15 by half 1).
+// bias + temb + residual enter through the accumulator init as in conv_wino_kernel (row 0 -> half 0, row 3 -> half 1).
+template <class C>
+__global__ __launch_bounds__(512, 2) void conv_wino8_kernel(const ConvParams p) {
+    constexpr int KC = C::KC, PS = C::PS, RS = C::RS, GPC = C::GPC, PF = C::PF;
+    constexpr int NP8 = 4;                                   // staging passes of 64 pixel slots
+    constexpr int LDS_FLOATS = 2 * C::BUF_FLOATS > 16384 ? 2 * C::BUF_FLOATS : 16384;   // halo double buffer / exchange image
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wh = wave & 1;
+
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int b = bx / p.tiles_y;
+    const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+
+    // ---- halo loader: 64 pixel slots x 8 channel quads.  Passes 0..2 = halo rows 2i, 2i+1 x columns 0..31, pass 3 =
+    // the two leftover columns of all six rows (12 slots) ----
+    static_assert(C::HH == 6 && C::HW == 34, "loader geometry is written for the 4 x 32 tile");
+    const int q = tid & 7, pl = tid >> 3;                    // pl in 0..63
+    const int prow = pl >> 5, pcol = pl & 31;
+    const int ixa = ix0 + pcol;
+    const bool colok = ixa >= 0 && ixa < Wv;
+    const int colx = colok ? (ixa >> p.ups) : 0;
+    const int iy3 = iy0 + (pl >> 1), ix3 = ix0 + 32 + (pl & 1);
+    const bool ok3 = pl < 12 && iy3 >= 0 && iy3 < Hv && ix3 >= 0 && ix3 < Wv;
+    const int soff3 = ok3 ? ((b * p.Hin + (iy3 >> p.ups)) * p.Win + (ix3 >> p.ups)) : 0;
+    const int wbase = prow * RS + pcol * PS + q * 4;          // + 2*i*RS
+    const int wbase3 = (pl >> 1) * RS + (32 + (pl & 1)) * PS + q * 4;
+    auto row_src = [&](int i) -> int {                        // per-thread (2 rows per pass): source row base or -1
+        const int iy = iy0 + 2 * i + prow;
+        return (iy >= 0 && iy < Hv) ? (b * p.Hin + (iy >> p.ups)) * p.Win : -1;
+    };
+    f32x4 pre[NP8];
+    f32x4 gsc, gsh;
+    bool cvalid;
+    auto issue_loads = [&](int chunk) {
+        const int s = chunk >= p.nchunk0;
+        const int cl = (s ? chunk - p.nchunk0 : chunk) * KC + q * 4;
+        const int cs = p.csrc[s];
+        cvalid = cl < cs;
+        const float* __restrict__ base = p.src[s] + (cvalid ? cl : 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int rs = row_src(i);
+            pre[i] = *reinterpret_cast<const f32x4*>(base + (size_t)((rs < 0 ? 0 : rs) + colx) * cs);
+        }
+        pre[3] = *reinterpret_cast<const f32x4*>(base + (size_t)soff3 * cs);
+        if (p.gn) {
+            const int cg = cvalid ? (s ? p.csrc[0] : 0) + cl : 0;
+            gsc = *reinterpret_cast<const f32x4*>(p.gscale + (size_t)b * p.ctot + cg);
+            gsh = *reinterpret_cast<const f32x4*>(p.gshift + (size_t)b * p.ctot + cg);
+        }
+    };
+    auto write_pass = [&](float* buf, int i) {
+        f32x4 v = pre[i];
+        const bool ok = cvalid && (i < 3 ? (colok && row_src(i) >= 0) : ok3);
+        if (p.gn) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], gsc[e], gsh[e]);
+        }
+        if (p.silu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f<false>(v[e]);
+        }
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < 3) *reinterpret_cast<f32x4*>(&buf[wbase + 2 * i * RS]) = v;
+        else if (pl < 12) *reinterpret_cast<f32x4*>(&buf[wbase3]) = v;
+    };
+
+    // ---- operand addressing: lane = (Winograd tile li, channel half lh); this wave reads patch rows wh..wh+2 ----
+    const int li = lane & 31, lh = lane >> 5;
+    const int wty = li >> 4, wtx = li & 15;
+    const int a_base = (2 * wty + wh) * RS + (2 * wtx) * PS + lh * 4;
+    const int ntile = blockIdx.y * 4 + wn;
+    const bool nvalid = ntile * 32 < p.Cout;
+    // packed weights [ntile][chunk][s][e][xiq][lane][4]: this wave uses xiq = 2*wh, 2*wh + 1
+    const float* __restrict__ wp = p.w + ((size_t)(nvalid ? ntile : 0) * p.nchunks) * 16384 + wh * 512;
+    const unsigned lane4 = lane * 4;
+    const int n = ntile * 32 + li;
+    const bool nok = nvalid && n < p.Cout;
+
+    // acc[2*x + j]: x = local V row (global row 2*wh + x), j = column
+    f32x16 acc[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    if (nok) {
+        float add = p.bias ? p.bias[n] : 0.f;
+        if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
+        // half 0 owns M[0][0] = R00 and M[0][3] = -R01; half 1 owns M[3][0] = -R10 and M[3][3] = R11
+        float rv[32];
+        if (p.residual) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int y = min(oy0 + 2 * (tile >> 4) + wh, p.Hout - 1);
+                const int x0 = min(ox0 + 2 * (tile & 15), p.Wout - 1), x1 = min(ox0 + 2 * (tile & 15) + 1, p.Wout - 1);
+                rv[2 * r] = p.residual[(((size_t)b * p.Hout + y) * p.Wout + x0) * p.Cout + n];
+                rv[2 * r + 1] = p.residual[(((size_t)b * p.Hout + y) * p.Wout + x1) * p.Cout + n];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) rv[k] = 0.f;
+        }
+        // (accumulator indices must be compile-time: a runtime-indexed register array is placed in scratch memory)
+        if (wh == 0) {       // global row 0 = local row 0: (+R00, -R01)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[0][r] = rv[2 * r] + add;
+                acc[3][r] = -(rv[2 * r + 1] + add);
+            }
+        } else {             // global row 3 = local row 1: (-R10, +R11)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[4][r] = -(rv[2 * r] + add);
+                acc[7][r] = rv[2 * r + 1] + add;
+            }
+        }
+    }
+
+    // weight ring: this wave consumes 2 fragments per group g = (s, e): f = 2*g + k, k = local xiq
+    constexpr int RF = 2 * PF;
+    f32x4 ring[RF];
+    auto foff = [](int f) { return (f >> 1) * 1024 + (f & 1) * 256; };     // float offset of fragment f inside a chunk
+#pragma unroll
+    for (int f = 0; f < RF; ++f) ring[f] = *reinterpret_cast<const f32x4*>(wp + foff(f) + lane4);
+
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    auto load_half = [&](const float* buf, int hh, f32x2 (&dst)[12]) {      // patch rows wh..wh+2, channels of half hh
+        int ab = a_base;
+        asm volatile("" : "+v"(ab));
+        __builtin_assume((ab & 1) == 0);
+        const int coff = (hh >> 1) * 8 + (hh & 1) * 2;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+                dst[a * 4 + bb] = *reinterpret_cast<const f32x2*>(&buf[ab + a * RS + bb * PS + coff]);
+    };
+    // the two V rows of this wave for channel c: rows (0,1) from patch rows (0,1,2); rows (2,3) from patch rows (1,2,3)
+    auto transform = [&](const f32x2 (&d)[12], int c, float (&v)[8]) {
+        float r0[4], r1[4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const float u0 = d[0 + bb][c], u1 = d[4 + bb][c], u2 = d[8 + bb][c];
+            if (wh == 0) {           // t0 = u0, t1 = u1, t2 = u2:  r[0] = t0 - t2, r[1] = t1 + t2
+                r0[bb] = u0 - u2;
+                r1[bb] = u1 + u2;
+            } else {                 // t1 = u0, t2 = u1, t3 = u2:  r[2] = t2 - t1, r[3] = t1 - t3
+                r0[bb] = u1 - u0;
+                r1[bb] = u0 - u2;
+            }
+        }
+        v[0] = r0[0] - r0[2]; v[1] = r0[1] + r0[2]; v[2] = r0[2] - r0[1]; v[3] = r0[1] - r0[3];
+        v[4] = r1[0] - r1[2]; v[5] = r1[1] + r1[2]; v[6] = r1[2] - r1[1]; v[7] = r1[1] - r1[3];
+    };
+
+    auto chunk_body = [&](const int chunk, const bool more) __attribute__((always_inline)) {
+        const float* cur = lds + (chunk & 1) * C::BUF_FLOATS;
+        float* nxt = lds + ((chunk + 1) & 1) * C::BUF_FLOATS;
+        const float* __restrict__ wc = wp + (size_t)chunk * 16384;
+        f32x2 dh[2][12];
+        float vv[2][8];
+        load_half(cur, 0, dh[0]);
+        transform(dh[0], 0, vv[0]);
+#pragma unroll
+        for (int g = 0; g < GPC; ++g) {
+            const int hh = g >> 1;
+            if ((g & 1) == 0 && hh + 1 < 8 && !(C::OPT & 2)) load_half(cur, hh + 1, dh[(hh + 1) & 1]);   // OPT 2: one half-load per chunk
+            if (g + 1 < GPC) {
+                if constexpr (C::OPT & 8) {      // OPT 8: no transform adds
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) vv[(g + 1) & 1][x] = dh[((g + 1) >> 1) & 1][x][(g + 1) & 1];
+                } else transform(dh[((g + 1) >> 1) & 1], (g + 1) & 1, vv[(g + 1) & 1]);
+            }
+            if (more && !(C::OPT & 4)) {      // OPT 4: no staging
+                constexpr int G0 = GPC - NP8 - 1;
+                if (g >= G0 && g < G0 + NP8) write_pass(nxt, g - G0);
+                if (g == G0 + NP8 && chunk + 2 < p.nchunks) issue_loads(chunk + 2);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int f = g * 2 + k;
+                const f32x4 bq = ring[f % RF];
+                if constexpr (!(C::OPT & 1))     // OPT 1: no weight refills
+                    ring[f % RF] = *reinterpret_cast<const f32x4*>((f + RF < 32 ? wc + foff(f + RF) : wc + 16384 + foff(f + RF - 32)) + lane4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[k * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[g & 1][k * 4 + j], bq[j], acc[k * 4 + j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- pipeline ----
+    issue_loads(0);
+#pragma unroll
+    for (int i = 0; i < NP8; ++i) write_pass(lds, i);
+    if (p.nchunks > 1) issue_loads(1);
+    __syncthreads();
+
+    if (!nvalid) {
+        for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+            if (chunk + 1 < p.nchunks) {
+#pragma unroll
+                for (int i = 0; i < NP8; ++i) write_pass(lds + ((chunk + 1) & 1) * C::BUF_FLOATS, i);
+                if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
+            }
+            __syncthreads();
+        }
+        __syncthreads();     // matches the exchange barrier below
+        return;
+    }
+    for (int chunk = 0; chunk + 1 < p.nchunks; ++chunk) {
+        chunk_body(chunk, true);
+        __syncthreads();
+    }
+    chunk_body(p.nchunks - 1, false);
+    __syncthreads();         // every wave is done with the halo buffers: they become the exchange image
+
+    // ---- partial output transform: this half's rows of M -> partial Y (linear), then swap halves through LDS ----
+    // tmp[0][j] = M0j + M1j + M2j, tmp[1][j] = M1j - M2j - M3j.  half 0 (rows 0,1): (M0j + M1j, M1j); half 1 (rows 2,3): (M2j, -M2j - M3j)
+    // exchange image: xch[wave][k = 0..31][lane]; registers 0..7 are finished by half 0, 8..15 by half 1.
+    float* xch = lds;
+    float mine[32];      // the 8 registers this wave finishes: partial y[4] each
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float t[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float m0 = acc[0 + j][r], m1 = acc[4 + j][r];          // local rows 0, 1
+            if (wh == 0) {
+                t[0][j] = m0 + m1;
+                t[1][j] = m1;
+            } else {
+                t[0][j] = m0;
+                t[1][j] = -m0 - m1;
+            }
+        }
+        float y[4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            y[a * 2 + 0] = t[a][0] + t[a][1] + t[a][2];
+            y[a * 2 + 1] = t[a][1] - t[a][2] - t[a][3];
+        }
+        const bool keep = (r >> 3) == wh;       // compile-time per r given wh is wave-uniform... (wh is runtime: select below)
+        const int rr = r & 7;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (keep) mine[rr * 4 + k] = y[k];
+            else xch[((wave * 32) + rr * 4 + k) * 64 + lane] = y[k];     // the partner finishes this register
+        }
+    }
+    __syncthreads();
+    {
+        const int partner = wave ^ 1;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) mine[k] += xch[((partner * 32) + k) * 64 + lane];
+    }
+
+    // ---- packed stores (quad transposes) of this wave's 8 tile-registers x 4 positions ----
+    int eoy0 = oy0, eox0 = ox0, elh = lh;
+    asm volatile("" : "+s"(eoy0), "+s"(eox0), "+v"(elh));
+    const int q4 = li & 3;
+    const int cq = ntile * 32 + (li & ~3);
+    const bool quad_ok = cq < p.Cout;
+    const bool vec_ok = (p.out_ld & 3) == 0 && cq + 4 <= p.out_ld;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {            // blocks of 4 registers: global registers 8*wh + 4*kk + i
+        const int tile = 8 * (2 * wh + kk) + q4 + 4 * elh;
+        const int oy = eoy0 + 2 * (tile >> 4), ox = eox0 + 2 * (tile & 15);
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            float x[4] = {mine[(4 * kk + 0) * 4 + pos], mine[(4 * kk + 1) * 4 + pos], mine[(4 * kk + 2) * 4 + pos], mine[(4 * kk + 3) * 4 + pos]};
+            quad_transpose(x, q4);
+            const int py = oy + (pos >> 1), px = ox + (pos & 1);
+            if (quad_ok && py < p.Hout && px < p.Wout) {
+                const size_t pix = ((size_t)b * p.Hout + py) * p.Wout + px;
+                if (vec_ok) *reinterpret_cast<f32x4*>(p.out + pix * p.out_ld + cq) = f32x4{x[0], x[1], x[2], x[3]};
+                else
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (cq + c < p.Cout) p.out[pix * p.out_ld + cq + c] = x[c];
+                if (p.stats) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double dv = (double)x[c];
+                        s1[c] += dv;
+                        s2[c] = fma(dv, dv, s2[c]);
+                    }
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        // slot = (tile, half): two slots per spatial tile (cdx_conv_stats_slots accounts for it)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            s1[c] += __shfl_xor(s1[c], 1);
+            s2[c] += __shfl_xor(s2[c], 1);
+            s1[c] += __shfl_xor(s1[c], 2);
+            s2[c] += __shfl_xor(s2[c], 2);
+            s1[c] += __shfl_xor(s1[c], 32);
+            s2[c] += __shfl_xor(s2[c], 32);
+        }
+        if (lh == 0 && q4 == 0 && quad_ok) {
+            const int slot = (ty * p.tiles_x + tx) * 2 + wh;
+            const int nslots = p.tiles_y * p.tiles_x * 2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (cq + c < p.Cout) {
+                    double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + cq + c) * 2;
+                    o[0] = s1[c];
+                    o[1] = s2[c];
+                }
+        }
+    }
+}
+
+template <class C>
+inline int conv_wino8_launch(const ConvParams& p, hipStream_t stream) {
+    dim3 grid(p.tiles_x * p.tiles_y * p.B, ceil_div(p.Cout, C::BN));
+    hipLaunchKernelGGL(conv_wino8_kernel<C>, grid, dim3(512), 0, stream, p);
+    return check_launch();
+}
+
 template <class C>
 inline int conv_wino_launch(const ConvParams& p, hipStream_t stream) {
     dim3 grid(p.tiles_x * p.tiles_y * p.B, ceil_div(p.Cout, C::BN));
