@@ -734,17 +734,19 @@ inline int conv_wino_persist_launch(const ConvParams& p, hipStream_t stream) {
 // A^T M A is linear in M: each half produces a partial 2x2 output per tile and the halves are summed once per tile
 // through LDS (registers 0..7 of a lane are finished by half 0, 8..15 by half 1).
 // bias + temb + residual enter through the accumulator init as in conv_wino_kernel (row 0 -> half 0, row 3 -> half 1).
-template <class C>
-__global__ __launch_bounds__(512, 2) void conv_wino8_kernel(const ConvParams p) {
+// (The body is a device function templated on the half WH: everything that depends on which V rows a wave owns is
+// resolved at compile time.  With a runtime `wh` hipcc if-converts the branches -- BOTH halves' transforms plus a
+// v_cndmask per value -- and a two-armed lambda inside one function re-creates the accumulator-phi spills.)
+template <class C, int WH>
+__device__ __forceinline__ void conv_wino8_body(const ConvParams& p, float* lds) {
     constexpr int KC = C::KC, PS = C::PS, RS = C::RS, GPC = C::GPC, PF = C::PF;
     constexpr int NP8 = 4;                                   // staging passes of 64 pixel slots
-    constexpr int LDS_FLOATS = 2 * C::BUF_FLOATS > 16384 ? 2 * C::BUF_FLOATS : 16384;   // halo double buffer / exchange image
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    constexpr int wh = WH;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 1, wh = wave & 1;
+    const int wn = wave >> 1;
 
     int bx = blockIdx.x;
     const int tx = bx % p.tiles_x;
@@ -846,7 +848,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(const ConvParams p) 
             for (int k = 0; k < 32; ++k) rv[k] = 0.f;
         }
         // (accumulator indices must be compile-time: a runtime-indexed register array is placed in scratch memory)
-        if (wh == 0) {       // global row 0 = local row 0: (+R00, -R01)
+        if constexpr (wh == 0) {   // global row 0 = local row 0: (+R00, -R01)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[0][r] = rv[2 * r] + add;
@@ -886,7 +888,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(const ConvParams p) 
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) {
             const float u0 = d[0 + bb][c], u1 = d[4 + bb][c], u2 = d[8 + bb][c];
-            if (wh == 0) {           // t0 = u0, t1 = u1, t2 = u2:  r[0] = t0 - t2, r[1] = t1 + t2
+            if constexpr (wh == 0) {   // t0 = u0, t1 = u1, t2 = u2:  r[0] = t0 - t2, r[1] = t1 + t2
                 r0[bb] = u0 - u2;
                 r1[bb] = u1 + u2;
             } else {                 // t1 = u0, t2 = u1, t3 = u2:  r[2] = t2 - t1, r[3] = t1 - t3
@@ -972,7 +974,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(const ConvParams p) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float m0 = acc[0 + j][r], m1 = acc[4 + j][r];          // local rows 0, 1
-            if (wh == 0) {
+            if constexpr (wh == 0) {
                 t[0][j] = m0 + m1;
                 t[1][j] = m1;
             } else {
@@ -986,7 +988,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(const ConvParams p) 
             y[a * 2 + 0] = t[a][0] + t[a][1] + t[a][2];
             y[a * 2 + 1] = t[a][1] - t[a][2] - t[a][3];
         }
-        const bool keep = (r >> 3) == wh;       // compile-time per r given wh is wave-uniform... (wh is runtime: select below)
+        const bool keep = (r >> 3) == wh;       // compile-time: registers 0..7 are finished by half 0, 8..15 by half 1
         const int rr = r & 7;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1059,6 +1061,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(const ConvParams p) 
                 }
         }
     }
+}
+
+template <class C>
+__global__ __launch_bounds__(512, 2) void conv_wino8_kernel(const ConvParams p) {
+    constexpr int LDS_FLOATS = 2 * C::BUF_FLOATS > 16384 ? 2 * C::BUF_FLOATS : 16384;   // halo double buffer / exchange image
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    // wave-uniform: both arms execute the same number of barriers
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) conv_wino8_body<C, 1>(p, lds);
+    else conv_wino8_body<C, 0>(p, lds);
 }
 
 template <class C>
