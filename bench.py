@@ -51,6 +51,16 @@ def conv_flops(a) -> float:
     return 2.0 * a.batch * a.hout * a.wout * a.cout * (a.c0 + a.c1) * a.ksize * a.ksize
 
 
+def conv_bytes(a, elem=4) -> float:
+    """Algorithmic HBM bytes of one conv launch: every input, residual and output element once, weights once."""
+    px_in = a.batch * a.hin * a.win
+    px_out = a.batch * a.hout * a.wout
+    b = px_in * (a.c0 + a.c1) * elem + px_out * a.cout * elem + a.cout * (a.c0 + a.c1) * a.ksize * a.ksize * elem
+    if a.residual:
+        b += px_out * a.cout * elem
+    return float(b)
+
+
 def plan_flops(plan) -> dict:
     """Algorithmic FLOPs of one forward, per op family (SURVEY.md section 8d formulas)."""
     out = {"conv": 0.0, "attn": 0.0, "linear": 0.0}
@@ -63,6 +73,10 @@ def plan_flops(plan) -> dict:
         elif n == "cdx_linear_f32":
             out["linear"] += 2.0 * a.m * a.n * a.k
     return out
+
+
+def fn_is_half(a) -> bool:
+    return type(a).__name__ == "ConvF16Args"
 
 
 def measure_dominant_kernel(plan, torch, reps=3):
@@ -88,8 +102,9 @@ def measure_dominant_kernel(plan, torch, reps=3):
             continue   # warm-up
         for a, e0, e1 in evs:
             ms = e0.elapsed_time(e1)
-            t = table.setdefault(conv_variant(a), {"flops": 0.0, "ms": 0.0, "launches": 0})
+            t = table.setdefault(conv_variant(a), {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0})
             t["flops"] += conv_flops(a)
+            t["bytes"] += conv_bytes(a, 2 if fn_is_half(a) else 4)
             t["ms"] += ms
             t["launches"] += 1
             sk = "k%ds%d %3dx%-3d %4d->%-4d %s" % (a.ksize, a.stride, a.hout, a.wout, a.c0 + a.c1, a.cout, conv_variant(a)[3])
@@ -113,13 +128,16 @@ def measure_dominant_kernel(plan, torch, reps=3):
                                   "frac can exceed 1; executed_* is the MFMA work actually issued" if wino else ""),
             "executed_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4),
             "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_forward": d["launches"] // reps,
-            "flop_share_of_forward": round(d["flops"] / sum(v["flops"] for v in table.values()), 4)}
+            "flop_share_of_forward": round(d["flops"] / sum(v["flops"] for v in table.values()), 4),
+            "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+            "hbm_GBps_at_algorithmic_bytes": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)}
     # HBM bytes per launch of this kernel: PMC counters cannot be read from inside the process, so the figure
     # comes from the committed rocprofv3 --pmc passes over this same command (profiles/r01_traffic.json).
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
         if wino and "wino" in tr["kernel"]:
             roof["traffic"] = round(tr["hbm_bytes_per_launch"])
+            roof["traffic_over_algorithmic"] = round(tr["hbm_bytes_per_launch"] / roof["algorithmic_bytes_per_launch"], 3)
             roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2 x FETCH + WRITE)"
     except (OSError, KeyError, ValueError):
         pass
