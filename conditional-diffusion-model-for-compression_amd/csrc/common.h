@@ -50,6 +50,24 @@ __device__ __forceinline__ void quad_transpose(float (&x)[4], int q) {
     x[3] = hi ? a3 : u1;
 }
 
+// Buffer addressing (scalar resource + 32-bit per-lane byte offset + SCALAR byte offset): the only addressing form
+// on gfx950 that costs no VALU instruction per access -- flat/global accesses from hipcc carry a 64-bit VALU add each,
+// and next to the f32 MFMA every VALU instruction is paid in full.  The resource spans 4 GiB
+// from `base`: callers put the 64-bit part of an address (image / tile / weight-tile base) into `base`.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+
 }  // namespace cdx
 
 #define CDX_REQUIRE(cond) \

@@ -822,6 +822,7 @@ __device__ __forceinline__ void conv_wino8_body(const ConvParams& p, float* lds)
     const unsigned lane4 = lane * 4;
     const int n = ntile * 32 + li;
     const bool nok = nvalid && n < p.Cout;
+    const bool full_tile = oy0 + C::TH <= p.Hout && ox0 + C::TW <= p.Wout;      // wave-uniform
 
     // acc[2*x + j]: x = local V row (global row 2*wh + x), j = column
     f32x16 acc[8];
@@ -834,7 +835,18 @@ __device__ __forceinline__ void conv_wino8_body(const ConvParams& p, float* lds)
         if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
         // half 0 owns M[0][0] = R00 and M[0][3] = -R01; half 1 owns M[3][0] = -R10 and M[3][3] = R11
         float rv[32];
-        if (p.residual) {
+        if (p.residual && full_tile) {
+            // tile wholly inside the image (the usual case): no clamps, and everything but one per-lane offset is
+            // wave-uniform -- 32 scalar bases (SALU) + one VGPR offset instead of 64-bit VALU address chains per load
+            const __amdgpu_buffer_rsrc_t rr = buf_rsrc(p.residual + (((size_t)b * p.Hout + oy0 + wh) * p.Wout + ox0) * p.Cout);
+            const unsigned voff = ((unsigned)(8 * lh) * (unsigned)p.Cout + (unsigned)n) * 4u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned pix = (unsigned)(2 * (r >> 3)) * (unsigned)p.Wout + (unsigned)(2 * ((r & 3) + 8 * ((r >> 2) & 1)));
+                rv[2 * r] = buf_load1(rr, voff, pix * (unsigned)p.Cout * 4u);
+                rv[2 * r + 1] = buf_load1(rr, voff, (pix + 1u) * (unsigned)p.Cout * 4u);
+            }
+        } else if (p.residual) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -867,8 +879,10 @@ __device__ __forceinline__ void conv_wino8_body(const ConvParams& p, float* lds)
     constexpr int RF = 2 * PF;
     f32x4 ring[RF];
     auto foff = [](int f) { return (f >> 1) * 1024 + (f & 1) * 256; };     // float offset of fragment f inside a chunk
+    const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(wp);                       // fragment address = scalar offset + lane * 16 B
+    const unsigned lane16 = lane * 16;
 #pragma unroll
-    for (int f = 0; f < RF; ++f) ring[f] = *reinterpret_cast<const f32x4*>(wp + foff(f) + lane4);
+    for (int f = 0; f < RF; ++f) ring[f] = buf_load4(wrs, lane16, foff(f) * 4u);
 
     using f32x2 = __attribute__((ext_vector_type(2))) float;
     auto load_half = [&](const float* buf, int hh, f32x2 (&dst)[12]) {      // patch rows wh..wh+2, channels of half hh
@@ -882,41 +896,66 @@ __device__ __forceinline__ void conv_wino8_body(const ConvParams& p, float* lds)
             for (int bb = 0; bb < 4; ++bb)
                 dst[a * 4 + bb] = *reinterpret_cast<const f32x2*>(&buf[ab + a * RS + bb * PS + coff]);
     };
-    // the two V rows of this wave for channel c: rows (0,1) from patch rows (0,1,2); rows (2,3) from patch rows (1,2,3)
-    auto transform = [&](const f32x2 (&d)[12], int c, float (&v)[8]) {
-        float r0[4], r1[4];
+    // the two V rows of this wave, for BOTH channels of a half at once (the channel pair a ds_read_b64 delivers is a
+    // 64-bit register pair, so every add of B^T d B is one v_pk_add_f32 = two results per VALU issue):
+    // rows (0,1) from patch rows (0,1,2); rows (2,3) from patch rows (1,2,3).  Same operation tree as the scalar form.
+    // (OPT 32: the adds as inline-asm v_pk_add_f32, which hipcc's post-RA peephole cannot split back into two
+    // scalar adds when they sit in the shadow of an MFMA.)
+    auto padd = [](f32x2 a, f32x2 b) -> f32x2 {
+        if constexpr (C::OPT & 32) {
+            f32x2 r;
+            asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+            return r;
+        } else return a + b;
+    };
+    auto psub = [](f32x2 a, f32x2 b) -> f32x2 {
+        if constexpr (C::OPT & 32) {
+            f32x2 r;
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+            return r;
+        } else return a - b;
+    };
+    auto transform2 = [&](const f32x2 (&d)[12], f32x2 (&v)[8]) {
+        f32x2 r0[4], r1[4];
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) {
-            const float u0 = d[0 + bb][c], u1 = d[4 + bb][c], u2 = d[8 + bb][c];
+            const f32x2 u0 = d[0 + bb], u1 = d[4 + bb], u2 = d[8 + bb];
             if constexpr (wh == 0) {   // t0 = u0, t1 = u1, t2 = u2:  r[0] = t0 - t2, r[1] = t1 + t2
-                r0[bb] = u0 - u2;
-                r1[bb] = u1 + u2;
+                r0[bb] = psub(u0, u2);
+                r1[bb] = padd(u1, u2);
             } else {                 // t1 = u0, t2 = u1, t3 = u2:  r[2] = t2 - t1, r[3] = t1 - t3
-                r0[bb] = u1 - u0;
-                r1[bb] = u0 - u2;
+                r0[bb] = psub(u1, u0);
+                r1[bb] = psub(u0, u2);
             }
         }
-        v[0] = r0[0] - r0[2]; v[1] = r0[1] + r0[2]; v[2] = r0[2] - r0[1]; v[3] = r0[1] - r0[3];
-        v[4] = r1[0] - r1[2]; v[5] = r1[1] + r1[2]; v[6] = r1[2] - r1[1]; v[7] = r1[1] - r1[3];
+        v[0] = psub(r0[0], r0[2]); v[1] = padd(r0[1], r0[2]); v[2] = psub(r0[2], r0[1]); v[3] = psub(r0[1], r0[3]);
+        v[4] = psub(r1[0], r1[2]); v[5] = padd(r1[1], r1[2]); v[6] = psub(r1[2], r1[1]); v[7] = psub(r1[1], r1[3]);
     };
 
+    // One chunk = 8 halves (channel pairs per lane) x 2 groups of 8 MFMAs.  Even group of half h: issue the LDS patch
+    // reads of half h+1 (single patch buffer: it was consumed one group earlier); odd group: transform them into the
+    // other operand set.  The second wave of the SIMD covers the LDS latency; a group is 512 MFMA cycles.
     auto chunk_body = [&](const int chunk, const bool more) __attribute__((always_inline)) {
         const float* cur = lds + (chunk & 1) * C::BUF_FLOATS;
         float* nxt = lds + ((chunk + 1) & 1) * C::BUF_FLOATS;
-        const float* __restrict__ wc = wp + (size_t)chunk * 16384;
-        f32x2 dh[2][12];
-        float vv[2][8];
-        load_half(cur, 0, dh[0]);
-        transform(dh[0], 0, vv[0]);
+        const unsigned wcb = (unsigned)chunk * 65536u;      // byte offset of this chunk's fragments
+        f32x2 dh[12];
+        f32x2 vv[2][8];
+        auto make_operands = [&](f32x2 (&v)[8]) {
+            if constexpr (C::OPT & 8) {          // OPT 8 (ablation): no transform adds
+#pragma unroll
+                for (int x = 0; x < 8; ++x) v[x] = dh[x];
+            } else transform2(dh, v);
+        };
+        load_half(cur, 0, dh);
+        make_operands(vv[0]);
 #pragma unroll
         for (int g = 0; g < GPC; ++g) {
             const int hh = g >> 1;
-            if ((g & 1) == 0 && hh + 1 < 8 && !(C::OPT & 2)) load_half(cur, hh + 1, dh[(hh + 1) & 1]);   // OPT 2: one half-load per chunk
-            if (g + 1 < GPC) {
-                if constexpr (C::OPT & 8) {      // OPT 8: no transform adds
-#pragma unroll
-                    for (int x = 0; x < 8; ++x) vv[(g + 1) & 1][x] = dh[((g + 1) >> 1) & 1][x][(g + 1) & 1];
-                } else transform(dh[((g + 1) >> 1) & 1], (g + 1) & 1, vv[(g + 1) & 1]);
+            if (hh + 1 < 8) {
+                if ((g & 1) == 0) {
+                    if (!(C::OPT & 2) || hh == 0) load_half(cur, hh + 1, dh);      // OPT 2 (ablation): one more half-load per chunk only
+                } else make_operands(vv[(hh + 1) & 1]);
             }
             if (more && !(C::OPT & 4)) {      // OPT 4: no staging
                 constexpr int G0 = GPC - NP8 - 1;
@@ -928,10 +967,10 @@ __device__ __forceinline__ void conv_wino8_body(const ConvParams& p, float* lds)
                 const int f = g * 2 + k;
                 const f32x4 bq = ring[f % RF];
                 if constexpr (!(C::OPT & 1))     // OPT 1: no weight refills
-                    ring[f % RF] = *reinterpret_cast<const f32x4*>((f + RF < 32 ? wc + foff(f + RF) : wc + 16384 + foff(f + RF - 32)) + lane4);
+                    ring[f % RF] = buf_load4(wrs, lane16, wcb + (f + RF < 32 ? foff(f + RF) : 16384 + foff(f + RF - 32)) * 4u);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[k * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[g & 1][k * 4 + j], bq[j], acc[k * 4 + j], 0, 0, 0);
+                    acc[k * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[hh & 1][k * 4 + j][g & 1], bq[j], acc[k * 4 + j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1011,6 +1050,30 @@ __device__ __forceinline__ void conv_wino8_body(const ConvParams& p, float* lds)
     const bool quad_ok = cq < p.Cout;
     const bool vec_ok = (p.out_ld & 3) == 0 && cq + 4 <= p.out_ld;
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    const bool fast_store = full_tile && vec_ok && ntile * 32 + 32 <= p.Cout;      // wave-uniform
+    if (fast_store) {
+        // scalar base per (kk, pos) + one per-lane offset: tile = 8*(2*wh + kk) + q4 + 4*lh -> row wh, column 8*kk + q4 + 4*lh
+        const __amdgpu_buffer_rsrc_t ro = buf_rsrc(p.out + (((size_t)b * p.Hout + eoy0 + 2 * wh) * p.Wout + eox0) * p.out_ld);
+        const unsigned voff = ((unsigned)(2 * (q4 + 4 * elh)) * (unsigned)p.out_ld + (unsigned)cq) * 4u;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int pos = 0; pos < 4; ++pos) {
+                float x[4] = {mine[(4 * kk + 0) * 4 + pos], mine[(4 * kk + 1) * 4 + pos], mine[(4 * kk + 2) * 4 + pos], mine[(4 * kk + 3) * 4 + pos]};
+                quad_transpose(x, q4);
+                const unsigned pix = (unsigned)(pos >> 1) * (unsigned)p.Wout + (unsigned)(16 * kk + (pos & 1));
+                buf_store4(ro, voff, pix * (unsigned)p.out_ld * 4u, f32x4{x[0], x[1], x[2], x[3]});
+                if (p.stats) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double dv = (double)x[c];
+                        s1[c] += dv;
+                        s2[c] = fma(dv, dv, s2[c]);
+                    }
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {            // blocks of 4 registers: global registers 8*wh + 4*kk + i
         const int tile = 8 * (2 * wh + kk) + q4 + 4 * elh;
