@@ -58,6 +58,10 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
 }
+// bounded: accesses at byte offsets >= `bytes` read 0 / are dropped (used to make padding lanes safe without clamps)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
 __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }

@@ -23,6 +23,9 @@ int conv_dispatch_wino(int variant, const ConvParams& p, hipStream_t stream) {
         case 48: return conv_wino8_launch<WinoCfg<2, 4>>(p, stream);    //   no staging
         case 49: return conv_wino8_launch<WinoCfg<2, 8>>(p, stream);    //   no transform adds
         case 50: return conv_wino8_launch<WinoCfg<2, 15>>(p, stream);   //   all of the above
+        case 52: return conv_wino8_launch<WinoCfg<2, 16>>(p, stream);   //   no epilogue
+        case 53: return conv_wino8_launch<WinoCfg<2, 256>>(p, stream);  //   no residual loads
+        case 54: return conv_wino8_launch<WinoCfg<2, 15 + 16 + 256>>(p, stream);   //   MFMA stream + prologue staging only
         case 51: return conv_wino8_launch<WinoCfg<2, 32>>(p, stream);   // transform adds pinned as v_pk_add_f32 (inline asm)
         case 34: return conv_wino_launch<WinoCfg<2, 64>>(p, stream);
         default: return CDX_ENOTSUP;

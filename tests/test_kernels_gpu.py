@@ -65,7 +65,7 @@ def tiles_for(k, s, wout=0):
         return (-1, 0, 1, 2)
     if s == 2:
         return (-1, 3, 4, 5)
-    return (-1, 0, 1, 2, 5, 6) + ((7, 31, 35) if wout >= 32 else ())     # 7 = Winograd (8-wave form); experimental ids: 31 = 4-wave form, 35 = persistent
+    return (-1, 0, 1, 2, 5, 6) + ((7, 31, 35) if wout >= 32 else ())     # 7 = Winograd (8-wave form); experimental ids: 31 = 4-wave form, 35 = persistent 4-wave form
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
@@ -117,9 +117,10 @@ def test_conv_fused_gn_silu_concat_temb_residual(cdx_mod, B, c0, c1, co, H, W, g
         close(got, want, 5e-6 if tile in (7, 31, 35) else 3e-6, f"fused conv tile {tile}")
 
 
-@pytest.mark.parametrize("B,ci,c_a,c_b,H,W,k,s", [(2, 32, 64, 32, 32, 32, 3, 1), (1, 64, 128, 0, 16, 16, 3, 1), (2, 32, 96, 64, 8, 8, 1, 1),
-                                                   (2, 32, 64, 0, 40, 24, 3, 2), (3, 32, 32, 32, 4, 4, 3, 1), (1, 32, 160, 0, 64, 64, 3, 1)])
-def test_conv_epilogue_stats_match_standalone_gn(cdx_mod, B, ci, c_a, c_b, H, W, k, s):
+@pytest.mark.parametrize("B,ci,c_a,c_b,H,W,k,s,tile", [(2, 32, 64, 32, 32, 32, 3, 1, -1), (1, 64, 128, 0, 16, 16, 3, 1, -1), (2, 32, 96, 64, 8, 8, 1, 1, -1),
+                                                        (2, 32, 64, 0, 40, 24, 3, 2, -1), (3, 32, 32, 32, 4, 4, 3, 1, -1), (1, 32, 160, 0, 64, 64, 3, 1, -1),
+                                                        (2, 32, 160, 128, 40, 72, 3, 1, 7), (3, 64, 128, 0, 8, 32, 3, 1, 7)])
+def test_conv_epilogue_stats_match_standalone_gn(cdx_mod, B, ci, c_a, c_b, H, W, k, s, tile):
     """GroupNorm statistics accumulated in the producing convs' epilogues (one or two producers = concat) give the
     same scale/shift as the standalone pass over the stored tensors, and as float64 torch."""
     ops = cdx_mod.ops
@@ -128,7 +129,7 @@ def test_conv_epilogue_stats_match_standalone_gn(cdx_mod, B, ci, c_a, c_b, H, W,
     for j, co in enumerate([c for c in (c_a, c_b) if c]):
         w = rnd(co, ci, k, k, seed=61 + j, scale=1.0 / math.sqrt(ci * k * k))
         pc = ops.PackedConv(w.numpy(), rnd(co, seed=63 + j).numpy() + 3.0, ci)      # biased: non-zero mean
-        o, st = ops.conv(pc, x, stride=s, want_stats=True)
+        o, st = ops.conv(pc, x, stride=s, want_stats=True, tile=tile)      # 7: the Winograd kernel (ragged tiles too)
         outs.append(o)
         stats.append(st)
     C = c_a + c_b
