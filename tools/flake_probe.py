@@ -1,0 +1,31 @@
+"""Flakiness probe: cycle through several conv shapes (fresh tensors each time, like the test-suite does), compare a
+Winograd variant (default: tile 7, the shipped one) with the 4-wave kernel (tile 31) on NaN-prefilled outputs and print
+the error pattern of every bad launch.   usage: tools/flake_probe.py [rounds] [tile]"""
+import sys, math, torch, numpy as np
+sys.path.insert(0, '/root/repo')
+import cdx
+from cdx import ops
+cases = [(2, 32, 128, 32, 32, 0), (2, 64, 128, 16, 16, 1), (1, 96, 128, 64, 64, 0), (2, 32, 160, 40, 72, 0), (1, 128, 128, 40, 64, 0)]
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+TILE = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+nbad = 0
+for rnd in range(rounds):
+    for ci_, (B, ci, co, H, W, up) in enumerate(cases):
+        g = torch.Generator().manual_seed(rnd * 10 + ci_)
+        x = torch.randn(B, H, W, ci, generator=g).cuda()
+        w = (np.random.default_rng(rnd).standard_normal((co, ci, 3, 3)) / math.sqrt(ci * 9)).astype(np.float32)
+        pc = ops.PackedConv(w, np.random.default_rng(3).standard_normal(co).astype(np.float32), ci)
+        ref = ops.conv(pc, x, upsample=bool(up), tile=31)
+        junk = torch.randn(1 << 20, device='cuda')      # perturb the allocator / caches
+        b = torch.full_like(ref, float('nan'))
+        ops.conv(pc, x, upsample=bool(up), tile=TILE, out=b)
+        d = (ref - b).abs()
+        d = torch.where(torch.isnan(d), torch.full_like(d, 1e9), d)
+        if d.max().item() > 1e-4:
+            nbad += 1
+            idx = (d > 1e-4).nonzero()
+            if nbad <= 6:
+                print('round', rnd, 'case', (B, ci, co, H, W, up), 'bad', len(idx), 'nan', int(torch.isnan(b).sum()),
+                      'img', sorted(set(idx[:, 0].tolist())), 'rows', sorted(set(idx[:, 1].tolist()))[:16],
+                      'cols', sorted(set(idx[:, 2].tolist()))[:40], 'ch', sorted(set(idx[:, 3].tolist()))[:40])
+print('bad launches', nbad, 'of', rounds * len(cases))
