@@ -98,6 +98,7 @@ Tile tile_of(int wcfg) {
         case WCFG_S32: return {wcfg, 32, 32, 1};
         case WCFG_S64: return {wcfg, 64, 32, 1};
         case WCFG_WINO: return {wcfg, 128, 128, 2};   // (wm = 2: the 8-wave kernel writes two GroupNorm slots per tile)
+        case WCFG_SMALL: return {wcfg, 256, 4, 1};     // 8 x 32 pixels, cout <= 4, vector-ALU kernel
         default: return {-1, 0, 0, 0};
     }
 }
@@ -105,6 +106,11 @@ Tile tile_of(int wcfg) {
 // Winograd F(2x2,3x3) applies to 3x3 stride-1 layers whose rows hold at least one 32-pixel tile row.
 bool wino_ok(const cdx_conv_args* a) {
     return a->ksize == 3 && a->stride == 1 && a->wout >= 32 && a->wpacked_wino != nullptr && aligned16(a->wpacked_wino);
+}
+
+// cout <= 4 (conv_out): the vector-ALU kernel of conv_small.hip (no GroupNorm sums of the output: nothing normalises it)
+bool small_ok(const cdx_conv_args* a) {
+    return a->ksize == 3 && a->stride == 1 && a->cout <= 4 && a->wout >= 32 && a->stats_out == nullptr;
 }
 
 // Tile-shape heuristic.  Depends on the LAYER shape only, never on the batch: a different tile changes the
@@ -119,6 +125,7 @@ Tile select_tile(const cdx_conv_args* a) {
         const int hw = a->hout * a->wout;
         if (hw <= kSplitKMaxPixels) t = tile_of(a->stride == 1 && hw >= 256 ? WCFG_S64 : WCFG_S32);
         else if (wino_ok(a) && a->cout >= 96) t = tile_of(WCFG_WINO);
+        else if (small_ok(a)) t = tile_of(WCFG_SMALL);
     }
     return t;
 }
@@ -127,6 +134,7 @@ bool tile_allowed(const cdx_conv_args* a, int wcfg) {
     if (a->ksize == 1) return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1;
     if (a->stride == 2) return wcfg == WCFG_1x4x2 || wcfg == WCFG_2x2x1 || wcfg == WCFG_S32;
     if (wcfg == WCFG_WINO) return wino_ok(a);
+    if (wcfg == WCFG_SMALL) return small_ok(a);
     return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1 || wcfg == WCFG_S32 || wcfg == WCFG_S64;
 }
 
@@ -210,6 +218,7 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
         p.w = a->wpacked_wino;
         return conv_dispatch_wino(experimental ? tile : 0, p, st);
     }
+    if (t.wcfg == WCFG_SMALL) return conv_dispatch_small(p, st);
     if (experimental) return conv_dispatch_exp(logtw, t.wcfg, p, st);
     if (a->ksize == 1) return conv_dispatch_k1s1(logtw, t.wcfg, p, st);
     if (a->stride == 1) return conv_dispatch_k3s1(logtw, t.wcfg, p, st);

@@ -1,0 +1,140 @@
+// 3x3 stride-1 convolution with at most 4 output channels (the UNet's conv_out: 128 -> 3 at full resolution).
+// With N = 3 a 32-wide MFMA tile wastes 29/32 of the matrix pipe (measured: 10.9 TF, 0.67 ms per forward at configs[1]);
+// here the products run on the vector ALU instead: thread = output pixel, the channel loop reads the same LDS halo
+// image the other kernels stage (GroupNorm / SiLU / upsample / concat fused while staging), and the weights -- uniform
+// across the wave -- come through the scalar cache straight out of the MFMA-packed image: for a (chunk, tap, s) group the
+// 64 bytes at lane 0 hold W[n = 0..3][channels 8s .. 8s+3] and the 64 bytes at lane 32 the channels 8s+4 .. 8s+7.
+// Every FMA takes its weight as an SGPR operand: 9 x Cin x NCO FMAs and 9 x Cin / 4 ds_read_b128 per pixel.
+// Bound: VALU (3456 FMA issues per wave at 128 -> 3), ~0.1 ms at configs[1].  No reference file exists to cite.
+#include "conv_kernel.h"
+
+namespace cdx {
+
+namespace {
+
+constexpr int S_TW = 32, S_TH = 8, S_HH = S_TH + 2, S_HW = S_TW + 2;
+constexpr int S_KC = CDX_CONV_KC, S_PS = S_KC + 4;
+constexpr int S_RS = ((S_HW * S_PS + 63) / 64) * 64;
+constexpr int S_NPIX = S_HH * S_HW, S_NPASS = (S_NPIX + 31) / 32;
+
+template <int NCO>
+__global__ __launch_bounds__(256, 2) void conv_small_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[S_HH * S_RS];
+    const int tid = threadIdx.x;
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int b = bx / p.tiles_y;
+    const int oy0 = ty * S_TH, ox0 = tx * S_TW;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+
+    // ---- halo loader: thread -> (pixel slot pl, channel quad q), S_NPASS passes of 32 slots ----
+    const int q = tid & 7, pl = tid >> 3;
+    int soff[S_NPASS];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int i = 0; i < S_NPASS; ++i) {
+        const int hp = i * 32 + pl;
+        const int hy = hp / S_HW, hx = hp - hy * S_HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool ok = hp < S_NPIX && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+        soff[i] = ok ? ((b * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups)) : 0;
+        vmask |= ok ? (1u << i) : 0u;
+    }
+    f32x4 pre[S_NPASS];
+    f32x4 gsc, gsh;
+    bool cvalid;
+    auto issue_loads = [&](int chunk) {
+        const int s = chunk >= p.nchunk0;
+        const int cl = (s ? chunk - p.nchunk0 : chunk) * S_KC + q * 4;
+        const int cs = p.csrc[s];
+        cvalid = cl < cs;
+        const float* __restrict__ base = p.src[s] + (cvalid ? cl : 0);      // padding lanes: safe address, zeroed at write time
+#pragma unroll
+        for (int i = 0; i < S_NPASS; ++i) pre[i] = *reinterpret_cast<const f32x4*>(base + (size_t)soff[i] * cs);
+        if (p.gn) {
+            const int cg = cvalid ? (s ? p.csrc[0] : 0) + cl : 0;
+            gsc = *reinterpret_cast<const f32x4*>(p.gscale + (size_t)b * p.ctot + cg);
+            gsh = *reinterpret_cast<const f32x4*>(p.gshift + (size_t)b * p.ctot + cg);
+        }
+    };
+    auto write_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < S_NPASS; ++i) {
+            const int hp = i * 32 + pl;
+            const int hy = hp / S_HW, hx = hp - hy * S_HW;
+            f32x4 v = pre[i];
+            const bool ok = cvalid && ((vmask >> i) & 1u);
+            if (p.gn) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], gsc[e], gsh[e]);
+            }
+            if (p.silu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f<false>(v[e]);
+            }
+            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (hp < S_NPIX) *reinterpret_cast<f32x4*>(&lds[hy * S_RS + hx * S_PS + q * 4]) = v;
+        }
+    };
+
+    const int py = tid >> 5, px = tid & 31;
+    const int a_base = py * S_RS + px * S_PS;
+    float acc[NCO];
+#pragma unroll
+    for (int n = 0; n < NCO; ++n) acc[n] = 0.f;
+
+    issue_loads(0);
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        write_lds();
+        __syncthreads();
+        if (chunk + 1 < p.nchunks) issue_loads(chunk + 1);
+        // packed weights of output tile 0: [chunk][tap][s][lane][4]; wave-uniform addresses -> scalar loads
+        const float* __restrict__ wc = p.w + (size_t)chunk * (9 * 1024);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(&lds[a_base + ky * S_RS + kx * S_PS + s * 8 + h * 4]);
+                    const float* __restrict__ wq = wc + (tap * 4 + s) * 256 + h * 128;      // [n][e]
+#pragma unroll
+                    for (int n = 0; n < NCO; ++n)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[n] = fmaf(a[e], wq[n * 4 + e], acc[n]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    const int oy = oy0 + py, ox = ox0 + px;
+    if (oy < p.Hout && ox < p.Wout) {
+        const size_t pix = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+#pragma unroll
+        for (int n = 0; n < NCO; ++n) {
+            if (n < p.Cout) {
+                float v = acc[n];
+                if (p.bias) v += p.bias[n];
+                if (p.temb) v += p.temb[(size_t)b * p.temb_ld + n];
+                if (p.residual) v += p.residual[pix * p.Cout + n];
+                p.out[pix * p.out_ld + n] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int conv_dispatch_small(const ConvParams& p, hipStream_t stream) {
+    dim3 grid(p.tiles_x * p.tiles_y * p.B, 1);
+    if (p.Cout <= 3) hipLaunchKernelGGL(conv_small_kernel<3>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(conv_small_kernel<4>, grid, dim3(256), 0, stream, p);
+    return check_launch();
+}
+
+}  // namespace cdx

@@ -113,46 +113,58 @@ __global__ __launch_bounds__(64) void gn_finalize(const double* __restrict__ par
 
 // Fused form: partial sums were left by the producing convolutions (conv_kernel epilogue), one slot per
 // (spatial tile, wave row); the two sources of a channel concat each bring their own slot count.
-__global__ __launch_bounds__(64) void gn_finalize2(const double* __restrict__ part0, int slots0, int c0,
-                                                   const double* __restrict__ part1, int slots1, int c1, int groups,
-                                                   int hw, float eps, const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta, float* __restrict__ scale,
-                                                   float* __restrict__ shift, float* __restrict__ mean_out,
-                                                   float* __restrict__ rstd_out) {
-    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+// One workgroup of 256 threads per (image, group).  A thread owns ONE channel of the group and every tpc-th slot
+// (tpc = 256 / channels-per-group): no index arithmetic in the loop, 4x the loads in flight of the one-wave version
+// (13 us average, 40 us at 256^2 where a group is 4 channels x 1024 slots = 64 KiB of 16-byte reads at 2 KiB stride).
+// Summation order is fixed by (thread, slot) and by the LDS tree below: results do not depend on timing or batch.
+__global__ __launch_bounds__(256) void gn_finalize2(const double* __restrict__ part0, int slots0, int c0,
+                                                    const double* __restrict__ part1, int slots1, int c1, int groups,
+                                                    int hw, float eps, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ scale,
+                                                    float* __restrict__ shift, float* __restrict__ mean_out,
+                                                    float* __restrict__ rstd_out) {
+    __shared__ double red[2][256];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int ctot = c0 + c1, cpg = ctot / groups;
-    const int cbeg = g * cpg, cend = cbeg + cpg;
+    const int cbeg = g * cpg;
+    const int tpc = cpg <= 256 ? 256 / cpg : 1;          // threads per channel
     double s = 0, ss = 0;
-    // channels of this group that live in source 0 / source 1
-    const int n0 = max(0, min(cend, c0) - cbeg), n1 = cpg - n0;
-    for (int it = lane; it < slots0 * n0; it += 64) {
-        const int slot = it / n0, c = cbeg + it % n0;
-        const double* q = part0 + (((size_t)b * slots0 + slot) * c0 + c) * 2;
-        s += q[0];
-        ss += q[1];
+    for (int k0 = 0; k0 < cpg; k0 += 256) {             // one pass unless a group has more than 256 channels
+        const int k = k0 + (cpg <= 256 ? tid % cpg : tid), j = cpg <= 256 ? tid / cpg : 0;
+        if (k < cpg && j < tpc) {
+            const int c = cbeg + k;
+            const bool src1 = c >= c0;
+            const int slots = src1 ? slots1 : slots0, cs = src1 ? c1 : c0;
+            const double* q = (src1 ? part1 : part0) + (((size_t)b * slots + j) * cs + (src1 ? c - c0 : c)) * 2;
+            const size_t step = (size_t)tpc * cs * 2;
+            for (int slot = j; slot < slots; slot += tpc, q += step) {
+                s += q[0];
+                ss += q[1];
+            }
+        }
     }
-    for (int it = lane; it < slots1 * n1; it += 64) {
-        const int slot = it / n1, c = max(cbeg, c0) - c0 + it % n1;
-        const double* q = part1 + (((size_t)b * slots1 + slot) * c1 + c) * 2;
-        s += q[0];
-        ss += q[1];
-    }
+    red[0][tid] = s;
+    red[1][tid] = ss;
+    __syncthreads();
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        s += __shfl_xor(s, off);
-        ss += __shfl_xor(ss, off);
+    for (int w = 128; w >= 1; w >>= 1) {
+        if (tid < w) {
+            red[0][tid] += red[0][tid + w];
+            red[1][tid] += red[1][tid + w];
+        }
+        __syncthreads();
     }
     const double n = (double)hw * cpg;
-    const double mean = s / n;
-    double var = ss / n - mean * mean;
+    const double mean = red[0][0] / n;
+    double var = red[1][0] / n - mean * mean;
     var = var < 0 ? 0 : var;
     const float meanf = (float)mean;
     const float rstdf = (float)(1.0 / sqrt(var + (double)eps));
-    if (lane == 0) {
+    if (tid == 0) {
         if (mean_out) mean_out[b * groups + g] = meanf;
         if (rstd_out) rstd_out[b * groups + g] = rstdf;
     }
-    for (int k = lane; k < cpg; k += 64) {
+    for (int k = tid; k < cpg; k += 256) {
         const int c = cbeg + k;
         const float sc = rstdf * gamma[c];
         scale[(size_t)b * ctot + c] = sc;
@@ -170,7 +182,7 @@ extern "C" int cdx_gn_finalize_f32(const cdx_gn_finalize_args* a, void*, size_t,
     CDX_REQUIRE((a->c1 == 0) == (a->part1 == nullptr));
     if (a->c1) CDX_REQUIRE(a->slots1 > 0);
     CDX_REQUIRE(a->batch > 0 && a->batch <= 65535 && a->hw > 0 && a->groups > 0 && (a->c0 + a->c1) % a->groups == 0);
-    hipLaunchKernelGGL(gn_finalize2, dim3(a->groups, a->batch), dim3(64), 0, static_cast<hipStream_t>(stream), a->part0,
+    hipLaunchKernelGGL(gn_finalize2, dim3(a->groups, a->batch), dim3(256), 0, static_cast<hipStream_t>(stream), a->part0,
                        a->slots0, a->c0, a->part1, a->slots1, a->c1, a->groups, a->hw, a->eps, a->gamma, a->beta, a->scale,
                        a->shift, a->mean, a->rstd);
     return check_launch();

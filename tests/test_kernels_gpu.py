@@ -47,7 +47,9 @@ CONV_CASES = [
     (2, 128, 64, 8, 8, 3, 1, False),       # TW=8, 2x2x2 wave layout
     (3, 32, 32, 4, 4, 3, 1, False),        # TW=4, 4x1x1 layout, image smaller than a tile
     (1, 8, 48, 40, 24, 3, 1, False),       # Cin < chunk (zero-filled), ragged H and W
-    (2, 32, 3, 32, 32, 3, 1, False),       # conv_out shape: cout = 3
+    (2, 32, 3, 32, 32, 3, 1, False),       # conv_out shape: cout = 3 (vector-ALU kernel, tile 8)
+    (1, 72, 4, 21, 45, 3, 1, False),       # cout = 4, ragged, Cin not a multiple of the chunk
+    (1, 64, 2, 16, 20, 3, 1, True),        # cout = 2 with the fused upsample (40 wide)
     (2, 64, 96, 32, 32, 1, 1, False),      # 1x1
     (1, 32, 256, 12, 20, 1, 1, False),     # 1x1 ragged
     (2, 32, 128, 32, 32, 3, 2, False),     # stride 2 (1x4x2)
@@ -58,14 +60,14 @@ CONV_CASES = [
 ]
 
 
-def tiles_for(k, s, wout=0):
+def tiles_for(k, s, wout=0, cout=999):
     """Every tile shape built for this ksize / stride (include/cdx.h CDX_TILE_*), plus -1 = the library's pick.
     Tile 7 = Winograd F(2x2,3x3) (3x3 stride 1, output width >= 32)."""
     if k == 1:
         return (-1, 0, 1, 2)
     if s == 2:
         return (-1, 3, 4, 5)
-    return (-1, 0, 1, 2, 5, 6) + ((7, 31, 35) if wout >= 32 else ())     # 7 = Winograd (8-wave form); experimental ids: 31 = 4-wave form, 35 = persistent 4-wave form
+    return (-1, 0, 1, 2, 5, 6) + ((8,) if wout >= 32 and cout <= 4 else ()) + ((7, 31, 35) if wout >= 32 else ())     # 7 = Winograd (8-wave form); experimental ids: 31 = 4-wave form, 35 = persistent 4-wave form
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
@@ -78,7 +80,7 @@ def test_conv_plain(cdx_mod, case):
     want = F.conv2d(xin, w.double(), bias.double(), stride=s, padding=k // 2)
     pc = cdx_mod.ops.PackedConv(w.numpy(), bias.numpy(), ci)
     xd = nhwc(x)
-    for tile in tiles_for(k, s, want.shape[-1]):
+    for tile in tiles_for(k, s, want.shape[-1], co):
         got = nchw(cdx_mod.ops.conv(pc, xd, stride=s, upsample=up, tile=tile))
         assert got.shape == want.shape
         close(got, want, 4e-6 if tile in (7, 31, 35) else 2e-6, f"conv tile {tile}")
@@ -90,6 +92,8 @@ def test_conv_plain(cdx_mod, case):
     (2, 64, 32, 64, 16, 16, 32),      # concat, group straddles the two sources (96/32 = 3 per group)
     (1, 128, 64, 96, 8, 8, 32),       # concat, 6 channels / group
     (2, 32, 0, 32, 4, 4, 8),
+    (1, 64, 32, 3, 40, 64, 32),       # conv_out-like: cout = 3, concat, vector-ALU kernel
+    (2, 128, 0, 3, 32, 32, 32),       # conv_out proper
 ])
 def test_conv_fused_gn_silu_concat_temb_residual(cdx_mod, B, c0, c1, co, H, W, groups):
     """The whole first half of a ResBlock in one launch pair: conv3x3(silu(gn(cat[x, skip]))) + bias +
@@ -112,7 +116,7 @@ def test_conv_fused_gn_silu_concat_temb_residual(cdx_mod, B, c0, c1, co, H, W, g
     close(mean.cpu(), xg.mean(-1), 1e-6, "gn mean")
     close(rstd.cpu(), (xg.var(-1, unbiased=False) + 1e-5).rsqrt(), 1e-6, "gn rstd")
     pc = ops.PackedConv(w.numpy(), bias.numpy(), c0, c1)
-    for tile in tiles_for(3, 1, W):
+    for tile in tiles_for(3, 1, W, co):
         got = nchw(ops.conv(pc, s0, s1, gn=(sc, sh), silu=True, temb=temb.cuda(), temb_off=2, residual=nhwc(res), tile=tile))
         close(got, want, 5e-6 if tile in (7, 31, 35) else 3e-6, f"fused conv tile {tile}")
 
