@@ -818,7 +818,6 @@ __device__ __forceinline__ void conv_wino8_body(const ConvParams& p, float* lds)
     const bool nvalid = ntile * 32 < p.Cout;
     // packed weights [ntile][chunk][s][e][xiq][lane][4]: this wave uses xiq = 2*wh, 2*wh + 1
     const float* __restrict__ wp = p.w + ((size_t)(nvalid ? ntile : 0) * p.nchunks) * 16384 + wh * 512;
-    const unsigned lane4 = lane * 4;
     const int n = ntile * 32 + li;
     const bool nok = nvalid && n < p.Cout;
     const bool full_tile = oy0 + C::TH <= p.Hout && ox0 + C::TW <= p.Wout;      // wave-uniform
@@ -1012,7 +1011,9 @@ __device__ __forceinline__ void conv_wino8_body(const ConvParams& p, float* lds)
 
     // ---- partial output transform: this half's rows of M -> partial Y (linear), then swap halves through LDS ----
     // tmp[0][j] = M0j + M1j + M2j, tmp[1][j] = M1j - M2j - M3j.  half 0 (rows 0,1): (M0j + M1j, M1j); half 1 (rows 2,3): (M2j, -M2j - M3j)
-    // exchange image: xch[wave][k = 0..31][lane]; registers 0..7 are finished by half 0, 8..15 by half 1.
+    // exchange image: xch[wave][lane][36]; registers 0..7 are finished by half 0, 8..15 by half 1.
+    // (36 floats per lane: 16-byte accesses at a 144-byte lane stride are bank-conflict free, as in the halo image)
+    constexpr int XS = 36;
     float* xch = lds;
     float mine[32];      // the 8 registers this wave finishes: partial y[4] each
 #pragma unroll
@@ -1037,106 +1038,118 @@ __device__ __forceinline__ void conv_wino8_body(const ConvParams& p, float* lds)
         }
         const bool keep = (r >> 3) == wh;       // compile-time: registers 0..7 are finished by half 0, 8..15 by half 1
         const int rr = r & 7;
+        if (keep) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (keep) mine[rr * 4 + k] = y[k];
-            else xch[((wave * 32) + rr * 4 + k) * 64 + lane] = y[k];     // the partner finishes this register
+            for (int k = 0; k < 4; ++k) mine[rr * 4 + k] = y[k];
+        } else {                                 // the partner finishes this register: one 16-byte write per register
+            *reinterpret_cast<f32x4*>(&xch[(wave * 64 + lane) * XS + rr * 4]) = f32x4{y[0], y[1], y[2], y[3]};
         }
     }
     __syncthreads();
     {
         const int partner = wave ^ 1;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) mine[k] += xch[((partner * 32) + k) * 64 + lane];
+        for (int rr = 0; rr < 8; ++rr) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(&xch[(partner * 64 + lane) * XS + rr * 4]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mine[rr * 4 + k] += o[k];
+        }
+    }
+
+    // ---- GroupNorm sums of the output: taken HERE, where a lane still owns one channel (n) at 32 pixels -- one double
+    // pair per lane and one lane-half exchange instead of four pairs and three exchanges after the transposes ----
+    if (p.stats) {
+        double s1 = 0.0, s2 = 0.0;
+        if (full_tile) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const double dv = (double)mine[k];
+                s1 += dv;
+                s2 = fma(dv, dv, s2);
+            }
+        } else {
+            // register r = 8*wh + rr -> tile (rr & 3) + 8*(rr >> 2) + 4*lh of tile row wh; value k -> pixel (2*wh + (k >> 1), 2*tilecol + (k & 1))
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool inside = oy0 + 2 * wh + (k >> 1) < p.Hout && ox0 + 2 * ((rr & 3) + 8 * (rr >> 2) + 4 * lh) + (k & 1) < p.Wout;
+                    const double dv = inside ? (double)mine[rr * 4 + k] : 0.0;      // branch-free: a zero adds nothing to either sum
+                    s1 += dv;
+                    s2 = fma(dv, dv, s2);
+                }
+        }
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lh == 0 && nok) {
+            // slot = (tile, half): two slots per spatial tile (cdx_conv_stats_slots accounts for it)
+            const int slot = (ty * p.tiles_x + tx) * 2 + wh;
+            const int nslots = p.tiles_y * p.tiles_x * 2;
+            double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + n) * 2;
+            o[0] = s1;
+            o[1] = s2;
+        }
     }
 
     // ---- packed stores (quad transposes) of this wave's 8 tile-registers x 4 positions ----
+    // All eight transposed vectors are formed FIRST and the eight stores are the LAST instructions of the wave: no
+    // register that a store reads is written again.  With transposes and stores interleaved, variants of this kernel
+    // returned -- in 1-15 % of launches, only from the second wave of a SIMD -- the last dword of the last lane quad of
+    // each 16-lane group of ONE store replaced by the next vector's value: the store's data registers were being
+    // re-written (ds_bpermute returns / v_cndmask of the next transpose) while the store still waited behind the other
+    // wave's stores.  Detector: tools/flake_probe.py and test_winograd_repeatable_across_launch_sequences; DESIGN.md section 8.
     int eoy0 = oy0, eox0 = ox0, elh = lh;
     asm volatile("" : "+s"(eoy0), "+s"(eox0), "+v"(elh));
     const int q4 = li & 3;
     const int cq = ntile * 32 + (li & ~3);
     const bool quad_ok = cq < p.Cout;
     const bool vec_ok = (p.out_ld & 3) == 0 && cq + 4 <= p.out_ld;
-    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     const bool fast_store = full_tile && vec_ok && ntile * 32 + 32 <= p.Cout;      // wave-uniform
+    f32x4 ov[8];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)            // blocks of 4 registers: global registers 8*wh + 4*kk + i
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            float x[4] = {mine[(4 * kk + 0) * 4 + pos], mine[(4 * kk + 1) * 4 + pos], mine[(4 * kk + 2) * 4 + pos], mine[(4 * kk + 3) * 4 + pos]};
+            quad_transpose(x, q4);
+            ov[kk * 4 + pos] = f32x4{x[0], x[1], x[2], x[3]};
+        }
+    __builtin_amdgcn_sched_barrier(0);
     if (fast_store) {
         // scalar base per (kk, pos) + one per-lane offset: tile = 8*(2*wh + kk) + q4 + 4*lh -> row wh, column 8*kk + q4 + 4*lh
         const __amdgpu_buffer_rsrc_t ro = buf_rsrc(p.out + (((size_t)b * p.Hout + eoy0 + 2 * wh) * p.Wout + eox0) * p.out_ld);
         const unsigned voff = ((unsigned)(2 * (q4 + 4 * elh)) * (unsigned)p.out_ld + (unsigned)cq) * 4u;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int pos = 0; pos < 4; ++pos) {
-                float x[4] = {mine[(4 * kk + 0) * 4 + pos], mine[(4 * kk + 1) * 4 + pos], mine[(4 * kk + 2) * 4 + pos], mine[(4 * kk + 3) * 4 + pos]};
-                quad_transpose(x, q4);
                 const unsigned pix = (unsigned)(pos >> 1) * (unsigned)p.Wout + (unsigned)(16 * kk + (pos & 1));
-                buf_store4(ro, voff, pix * (unsigned)p.out_ld * 4u, f32x4{x[0], x[1], x[2], x[3]});
-                if (p.stats) {
+                buf_store4(ro, voff, pix * (unsigned)p.out_ld * 4u, ov[kk * 4 + pos]);
+            }
+    } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const double dv = (double)x[c];
-                        s1[c] += dv;
-                        s2[c] = fma(dv, dv, s2[c]);
-                    }
+        for (int kk = 0; kk < 2; ++kk) {
+            const int tile = 8 * (2 * wh + kk) + q4 + 4 * elh;
+            const int oy = eoy0 + 2 * (tile >> 4), ox = eox0 + 2 * (tile & 15);
+#pragma unroll
+            for (int pos = 0; pos < 4; ++pos) {
+                const int py = oy + (pos >> 1), px = ox + (pos & 1);
+                if (quad_ok && py < p.Hout && px < p.Wout) {
+                    const size_t pix = ((size_t)b * p.Hout + py) * p.Wout + px;
+                    if (vec_ok) *reinterpret_cast<f32x4*>(p.out + pix * p.out_ld + cq) = ov[kk * 4 + pos];
+                    else
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (cq + c < p.Cout) p.out[pix * p.out_ld + cq + c] = ov[kk * 4 + pos][c];
                 }
             }
-        }
-    } else
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {            // blocks of 4 registers: global registers 8*wh + 4*kk + i
-        const int tile = 8 * (2 * wh + kk) + q4 + 4 * elh;
-        const int oy = eoy0 + 2 * (tile >> 4), ox = eox0 + 2 * (tile & 15);
-#pragma unroll
-        for (int pos = 0; pos < 4; ++pos) {
-            float x[4] = {mine[(4 * kk + 0) * 4 + pos], mine[(4 * kk + 1) * 4 + pos], mine[(4 * kk + 2) * 4 + pos], mine[(4 * kk + 3) * 4 + pos]};
-            quad_transpose(x, q4);
-            const int py = oy + (pos >> 1), px = ox + (pos & 1);
-            if (quad_ok && py < p.Hout && px < p.Wout) {
-                const size_t pix = ((size_t)b * p.Hout + py) * p.Wout + px;
-                if (vec_ok) *reinterpret_cast<f32x4*>(p.out + pix * p.out_ld + cq) = f32x4{x[0], x[1], x[2], x[3]};
-                else
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (cq + c < p.Cout) p.out[pix * p.out_ld + cq + c] = x[c];
-                if (p.stats) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const double dv = (double)x[c];
-                        s1[c] += dv;
-                        s2[c] = fma(dv, dv, s2[c]);
-                    }
-                }
-            }
-        }
-    }
-    if (p.stats) {
-        // slot = (tile, half): two slots per spatial tile (cdx_conv_stats_slots accounts for it)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            s1[c] += __shfl_xor(s1[c], 1);
-            s2[c] += __shfl_xor(s2[c], 1);
-            s1[c] += __shfl_xor(s1[c], 2);
-            s2[c] += __shfl_xor(s2[c], 2);
-            s1[c] += __shfl_xor(s1[c], 32);
-            s2[c] += __shfl_xor(s2[c], 32);
-        }
-        if (lh == 0 && q4 == 0 && quad_ok) {
-            const int slot = (ty * p.tiles_x + tx) * 2 + wh;
-            const int nslots = p.tiles_y * p.tiles_x * 2;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (cq + c < p.Cout) {
-                    double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + cq + c) * 2;
-                    o[0] = s1[c];
-                    o[1] = s2[c];
-                }
         }
     }
 }
 
 template <class C>
 __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(const ConvParams p) {
-    constexpr int LDS_FLOATS = 2 * C::BUF_FLOATS > 16384 ? 2 * C::BUF_FLOATS : 16384;   // halo double buffer / exchange image
+    constexpr int LDS_FLOATS = 2 * C::BUF_FLOATS > 8 * 64 * 36 ? 2 * C::BUF_FLOATS : 8 * 64 * 36;   // halo double buffer / exchange image
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     // wave-uniform: both arms execute the same number of barriers
     if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) conv_wino8_body<C, 1>(p, lds);
