@@ -159,9 +159,11 @@ def test_winograd_repeatable_across_launch_sequences(cdx_mod):
             x = nhwc(rnd(B, ci, H, W, seed=1000 + 10 * rnd_i + j))
             w = rnd(co, ci, 3, 3, seed=2000 + rnd_i, scale=1.0 / math.sqrt(ci * 9))
             pc = ops.PackedConv(w.numpy(), rnd(co, seed=3).numpy(), ci)
-            ref = ops.conv(pc, x, upsample=up, tile=31)
+            ho, wo = (H * 2, W * 2) if up else (H, W)
+            kw = dict(residual=nhwc(rnd(B, co, ho, wo, seed=3000 + rnd_i)), temb=rnd(B, co, seed=4000 + rnd_i).cuda()) if rnd_i & 1 else {}
+            ref = ops.conv(pc, x, upsample=up, tile=31, **kw)      # odd rounds: + temb + residual (the LDS-DMA path)
             got = torch.full_like(ref, float("nan"))
-            ops.conv(pc, x, upsample=up, tile=7, out=got)
+            ops.conv(pc, x, upsample=up, tile=7, out=got, **kw)
             assert not torch.isnan(got).any(), f"round {rnd_i} case {j}: unwritten outputs"
             err = (got - ref).abs().max().item()
             assert err <= 2e-5 * max(ref.abs().max().item(), 1.0), f"round {rnd_i} case {j}: max abs diff {err:.3e}"

@@ -15,15 +15,17 @@ for rnd in range(rounds):
         x = torch.randn(B, H, W, ci, generator=g).cuda()
         w = (np.random.default_rng(rnd).standard_normal((co, ci, 3, 3)) / math.sqrt(ci * 9)).astype(np.float32)
         pc = ops.PackedConv(w, np.random.default_rng(3).standard_normal(co).astype(np.float32), ci)
-        ref = ops.conv(pc, x, upsample=bool(up), tile=31)
+        ho, wo = (H * 2, W * 2) if up else (H, W)
+        kw = dict(residual=torch.randn(B, ho, wo, co, generator=g).cuda(), temb=torch.randn(B, co, generator=g).cuda()) if (rnd & 1) else {}
+        ref = ops.conv(pc, x, upsample=bool(up), tile=31, **kw)      # odd rounds: + temb + residual (the LDS-DMA path)
         junk = torch.randn(1 << 20, device='cuda')      # perturb the allocator / caches
         b = torch.full_like(ref, float('nan'))
-        ops.conv(pc, x, upsample=bool(up), tile=TILE, out=b)
+        ops.conv(pc, x, upsample=bool(up), tile=TILE, out=b, **kw)
         d = (ref - b).abs()
         d = torch.where(torch.isnan(d), torch.full_like(d, 1e9), d)
-        if d.max().item() > 1e-4:
+        if d.max().item() > 1e-4 * max(1.0, ref.abs().max().item()):
             nbad += 1
-            idx = (d > 1e-4).nonzero()
+            idx = (d > 1e-4 * max(1.0, ref.abs().max().item())).nonzero()
             if nbad <= 6:
                 print('round', rnd, 'case', (B, ci, co, H, W, up), 'bad', len(idx), 'nan', int(torch.isnan(b).sum()),
                       'img', sorted(set(idx[:, 0].tolist())), 'rows', sorted(set(idx[:, 1].tolist()))[:16],
