@@ -121,8 +121,13 @@ Tile select_tile(const cdx_conv_args* a) {
     else t = tile_of(a->cout <= 32 ? WCFG_4x1x1 : a->cout <= 64 ? WCFG_2x2x2 : WCFG_1x4x4);
     // Low-resolution levels: 128-pixel tiles would give far fewer workgroups than the chip has CUs (8^2 x
     // 512 ch at batch 16 = 32 tiles of 128 x 128).  Use 32/64-pixel x 32-channel tiles whose 4 waves split K.
+    const int hw = a->hout * a->wout;
+    if (a->ksize == 1 && a->wout < 32) {
+        // 1x1 at the low-resolution levels (attention qkv / proj, skip projections): measured at batch 16, 512 channels:
+        // 8^2: 128x128 14 TF, 128x32 25, S32x32 50;  16^2: 128x128 48 TF, 128x64 65, S32x32 62
+        t = tile_of(hw <= 64 ? WCFG_S32 : hw <= 256 ? WCFG_2x2x2 : t.wcfg);
+    }
     if (a->ksize == 3) {
-        const int hw = a->hout * a->wout;
         if (hw <= kSplitKMaxPixels) t = tile_of(a->stride == 1 && hw >= 256 ? WCFG_S64 : WCFG_S32);
         else if (wino_ok(a) && a->cout >= 96) t = tile_of(WCFG_WINO);
         else if (small_ok(a)) t = tile_of(WCFG_SMALL);
@@ -131,7 +136,7 @@ Tile select_tile(const cdx_conv_args* a) {
 }
 
 bool tile_allowed(const cdx_conv_args* a, int wcfg) {
-    if (a->ksize == 1) return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1;
+    if (a->ksize == 1) return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1 || ((wcfg == WCFG_S32 || wcfg == WCFG_S64) && a->wout < 32);
     if (a->stride == 2) return wcfg == WCFG_1x4x2 || wcfg == WCFG_2x2x1 || wcfg == WCFG_S32;
     if (wcfg == WCFG_WINO) return wino_ok(a);
     if (wcfg == WCFG_SMALL) return small_ok(a);

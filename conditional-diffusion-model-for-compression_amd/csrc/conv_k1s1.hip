@@ -6,12 +6,18 @@ namespace cdx {
     CDX_CONV_CASE(KS, ST, 2, 0, 1, 4, 4, 1, 4, OPT_OCC2) \
     CDX_CONV_CASE(KS, ST, 2, 1, 2, 2, 2) \
     CDX_CONV_CASE(KS, ST, 2, 2, 4, 1, 1) \
+    CDX_CONV_CASE(KS, ST, 2, 5, 1, 1, 1, 4, 1) \
+    CDX_CONV_CASE(KS, ST, 2, 6, 1, 1, 2, 4, 1) \
     CDX_CONV_CASE(KS, ST, 3, 0, 1, 4, 4, 1, 4, OPT_OCC2) \
     CDX_CONV_CASE(KS, ST, 3, 1, 2, 2, 2) \
     CDX_CONV_CASE(KS, ST, 3, 2, 4, 1, 1) \
+    CDX_CONV_CASE(KS, ST, 3, 5, 1, 1, 1, 4, 1) \
+    CDX_CONV_CASE(KS, ST, 3, 6, 1, 1, 2, 4, 1) \
     CDX_CONV_CASE(KS, ST, 4, 0, 1, 4, 4, 1, 4, OPT_OCC2) \
     CDX_CONV_CASE(KS, ST, 4, 1, 2, 2, 2) \
     CDX_CONV_CASE(KS, ST, 4, 2, 4, 1, 1) \
+    CDX_CONV_CASE(KS, ST, 4, 5, 1, 1, 1, 4, 1) \
+    CDX_CONV_CASE(KS, ST, 4, 6, 1, 1, 2, 4, 1) \
     CDX_CONV_CASE(KS, ST, 5, 0, 1, 4, 4, 1, 4, OPT_OCC2) \
     CDX_CONV_CASE(KS, ST, 5, 1, 2, 2, 2) \
     CDX_CONV_CASE(KS, ST, 5, 2, 4, 1, 1) \

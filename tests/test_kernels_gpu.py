@@ -52,6 +52,7 @@ CONV_CASES = [
     (1, 64, 2, 16, 20, 3, 1, True),        # cout = 2 with the fused upsample (40 wide)
     (2, 64, 96, 32, 32, 1, 1, False),      # 1x1
     (1, 32, 256, 12, 20, 1, 1, False),     # 1x1 ragged
+    (2, 96, 160, 8, 8, 1, 1, False),       # 1x1 at 8^2: split-K tile by default, 3 chunks over 4 waves
     (2, 32, 128, 32, 32, 3, 2, False),     # stride 2 (1x4x2)
     (1, 64, 64, 18, 10, 3, 2, False),      # stride 2, odd-ish sizes, 2x2x1
     (2, 32, 128, 16, 16, 3, 1, True),      # nearest-2x upsample fused
@@ -64,7 +65,7 @@ def tiles_for(k, s, wout=0, cout=999):
     """Every tile shape built for this ksize / stride (include/cdx.h CDX_TILE_*), plus -1 = the library's pick.
     Tile 7 = Winograd F(2x2,3x3) (3x3 stride 1, output width >= 32)."""
     if k == 1:
-        return (-1, 0, 1, 2)
+        return (-1, 0, 1, 2) + ((5, 6) if wout < 32 else ())
     if s == 2:
         return (-1, 3, 4, 5)
     return (-1, 0, 1, 2, 5, 6) + ((8,) if wout >= 32 and cout <= 4 else ()) + ((7, 31, 35) if wout >= 32 else ())     # 7 = Winograd (8-wave form); experimental ids: 31 = 4-wave form, 35 = persistent 4-wave form
