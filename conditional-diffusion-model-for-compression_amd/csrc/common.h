@@ -38,12 +38,20 @@ __host__ __device__ inline uint64_t stream_key(uint64_t seed, uint64_t a, uint64
 // on exit lane q holds x[j] = value(row q, col j).  Two butterfly stages (xor 1, xor 2 -> DPP quad permutes).
 // Used by the convolution epilogues: accumulator layout (lane = channel, register = pixel) -> (lane = pixel, 4
 // consecutive channels in registers), so outputs / residuals move as 8- or 16-byte accesses instead of 2- or 4-byte.
+// (the lane exchanges are DPP quad permutes -- one VALU move each, no LDS round trip: __shfl_xor compiles to
+// ds_bpermute_b32 + an lgkmcnt wait, and the epilogues are VALU/issue-bound)
+__device__ __forceinline__ float quad_xor1(float v) {      // value of lane ^ 1: quad_perm [1,0,3,2]
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {      // value of lane ^ 2: quad_perm [2,3,0,1]
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
 __device__ __forceinline__ void quad_transpose(float (&x)[4], int q) {
     const bool odd = q & 1;
-    const float r0 = __shfl_xor(odd ? x[0] : x[1], 1), r1 = __shfl_xor(odd ? x[2] : x[3], 1);
+    const float r0 = quad_xor1(odd ? x[0] : x[1]), r1 = quad_xor1(odd ? x[2] : x[3]);
     const float a0 = odd ? r0 : x[0], a1 = odd ? x[1] : r0, a2 = odd ? r1 : x[2], a3 = odd ? x[3] : r1;
     const bool hi = q & 2;
-    const float u0 = __shfl_xor(hi ? a0 : a2, 2), u1 = __shfl_xor(hi ? a1 : a3, 2);
+    const float u0 = quad_xor2(hi ? a0 : a2), u1 = quad_xor2(hi ? a1 : a3);
     x[0] = hi ? u0 : a0;
     x[1] = hi ? u1 : a1;
     x[2] = hi ? a2 : u0;
