@@ -1,8 +1,11 @@
-// WORK IN PROGRESS -- NOT COMPILED INTO libcdx.so, NOT VALIDATED.
+// WORK IN PROGRESS -- NOT COMPILED INTO libcdx.so.
 // Persistent form of the 8-wave Winograd kernel (one workgroup per CU walks tiles; next tile's halo / residual fetched
 // under the current tile; stores drain under the next tile).  State when parked: compiles to 256 VGPRs with ~170 spilled
-// VGPRs and ~80 spilled SGPRs, and fails parity non-deterministically in output lanes 12/28 (+32) of waves 4..7
-// (cause not found).  To resume: paste into conv_wino.h before conv_wino8_launch and add a variant id in conv_wino.hip.
+// VGPRs and ~80 spilled SGPRs (loader state, ring and in-flight loads live across the epilogue), and its parity failure
+// (16 wrong values per bad launch) was the store-data hazard described in DESIGN.md section 8: its epilogue interleaves
+// quad transposes and 16-byte stores, so the rule "registers read by a store are not written again" must be applied
+// before it is revived.  Expected gain if the spills are removed: the tile turnaround only (~3-5 % of the kernel); the
+// LDS-DMA residual path measured no gain on the non-persistent kernel.
 // ------------------------------------------------------------------------------------------------------------
 // Persistent 8-wave form (experiment).  Measured on the non-persistent 8-wave kernel:
 // of a 47 us four-chunk tile, ~4 us is the residual tile being fetched before the first MFMA and ~5 us the output
