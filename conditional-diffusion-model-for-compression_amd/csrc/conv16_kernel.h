@@ -76,7 +76,10 @@ template <class C>
 __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     constexpr int KC = C::KC, PSH = C::PSH, RSH = C::RSH, TAPS = C::TAPS, MT = C::MT, NPASS = C::NPASS, GPC = C::GPC;
     constexpr int PF = C::PF < GPC ? C::PF : GPC;
-    __shared__ __attribute__((aligned(16))) _Float16 lds[C::LDS_HALVES];
+    // two halo images: chunk c+1 is staged into the other one WHILE chunk c's MFMAs run (one pass per MFMA group), one
+    // barrier per chunk -- the f16 MFMA leaves the vector ALU free (unlike the f32 one), so the GroupNorm / SiLU /
+    // fp16-rounding work of the staging hides under it instead of standing between two barriers.
+    __shared__ __attribute__((aligned(16))) _Float16 lds_all[2 * C::LDS_HALVES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -148,9 +151,8 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
         }
     };
 
-    auto write_lds = [&]() {
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
+    auto write_pass = [&](_Float16* lds, int i) {
+        {
             const int hp = i * 64 + pl;
             const int hy = hp / C::HW, hx = hp - hy * C::HW;
             const bool ok = cvalid && ((vmask >> i) & 1u);
@@ -189,16 +191,34 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     const int q4 = li & 3;
     const int cq = ntile * 32 + (li & ~3);                    // first of this quad's 4 channels
     const bool quad_ok = nvalid && cq < p.Cout;               // (cout is a multiple of 4 or the tail is zero-weighted)
+    // staging schedule inside a chunk: passes at groups G0 .. G0+NPASS-1, the loads of the chunk after next right behind
+    constexpr int G0 = GPC > NPASS + 1 ? GPC - NPASS - 1 : 0;
+    static_assert(NPASS + 1 <= GPC || GPC <= 2, "staging passes must fit in the chunk's groups (1x1: done after the groups)");
     issue_loads(0);
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
+    if (p.nchunks > 1 && !(C::ABL & 2)) issue_loads(1);
+    __syncthreads();
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        if (!(C::ABL & 2) || chunk == 0) write_lds();
-        __syncthreads();
-        if (!(C::ABL & 2))
-            if (chunk + 1 < p.nchunks) issue_loads(chunk + 1);
+        const _Float16* lds = lds_all + (chunk & 1) * C::LDS_HALVES;
+        _Float16* nxt = lds_all + ((chunk + 1) & 1) * C::LDS_HALVES;
+        const bool more = chunk + 1 < p.nchunks && !(C::ABL & 2);
+        if (!nvalid || GPC <= 2) {
+            // a wave without output channels (or a 1x1 layer: two groups per chunk) stages in one go
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < NPASS; ++i) write_pass(nxt, i);
+                if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
+            }
+        }
         if (nvalid) {
             const _Float16* __restrict__ wc = wp + (size_t)chunk * (TAPS * 1024);
 #pragma unroll
             for (int g = 0; g < GPC; ++g) {
+                if (GPC > 2 && more) {
+                    if (g >= G0 && g < G0 + NPASS) write_pass(nxt, g - G0);
+                    if (g == G0 + NPASS && chunk + 2 < p.nchunks) issue_loads(chunk + 2);
+                }
                 const int tap = g >> 1, j = g & 1, ky = tap / C::KS, kx = tap % C::KS;
                 int ab = a_base;
                 asm volatile("" : "+v"(ab));                 // no cross-tap CSE of LDS reads (see conv_kernel.h)
