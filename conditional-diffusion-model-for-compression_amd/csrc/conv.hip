@@ -98,7 +98,8 @@ Tile tile_of(int wcfg) {
         case WCFG_S32: return {wcfg, 32, 32, 1};
         case WCFG_S64: return {wcfg, 64, 32, 1};
         case WCFG_WINO: return {wcfg, 128, 128, 2};   // (wm = 2: the 8-wave kernel writes two GroupNorm slots per tile)
-        case WCFG_SMALL: return {wcfg, 256, 4, 1};     // 8 x 32 pixels, cout <= 4, vector-ALU kernel
+        case WCFG_SMALL: return {wcfg, 256, 4, 1};     // 8 x 32 pixels, cout <= 4 (4x4x1 MFMA form)
+        case WCFG_SMALL_VALU: return {wcfg, 256, 4, 1};   // same tile, vector-ALU form (scalar-cache weights)
         default: return {-1, 0, 0, 0};
     }
 }
@@ -139,7 +140,7 @@ bool tile_allowed(const cdx_conv_args* a, int wcfg) {
     if (a->ksize == 1) return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1 || ((wcfg == WCFG_S32 || wcfg == WCFG_S64) && a->wout < 32);
     if (a->stride == 2) return wcfg == WCFG_1x4x2 || wcfg == WCFG_2x2x1 || wcfg == WCFG_S32;
     if (wcfg == WCFG_WINO) return wino_ok(a);
-    if (wcfg == WCFG_SMALL) return small_ok(a);
+    if (wcfg == WCFG_SMALL || wcfg == WCFG_SMALL_VALU) return small_ok(a);
     return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1 || wcfg == WCFG_S32 || wcfg == WCFG_S64;
 }
 
@@ -223,7 +224,7 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
         p.w = a->wpacked_wino;
         return conv_dispatch_wino(experimental ? tile : 0, p, st);
     }
-    if (t.wcfg == WCFG_SMALL) return conv_dispatch_small(p, st);
+    if (t.wcfg == WCFG_SMALL || t.wcfg == WCFG_SMALL_VALU) return conv_dispatch_small(p, st, t.wcfg == WCFG_SMALL_VALU);
     if (experimental) return conv_dispatch_exp(logtw, t.wcfg, p, st);
     if (a->ksize == 1) return conv_dispatch_k1s1(logtw, t.wcfg, p, st);
     if (a->stride == 1) return conv_dispatch_k3s1(logtw, t.wcfg, p, st);

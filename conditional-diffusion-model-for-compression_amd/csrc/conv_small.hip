@@ -128,12 +128,139 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const ConvParams p) 
     }
 }
 
+// MFMA form: v_mfma_f32_4x4x1_16B_f32 = 16 independent 4x4 outer products per instruction.  Block b = lanes 4b..4b+3 =
+// four consecutive pixels; A[i] = the activation of pixel 4b+i (each lane's own LDS read), B[j] = W[channel][cout j]
+// (lane 4b+j reads the 16 bytes W[j][4 channels] of the chunk's weight image in LDS), D[i][j] accumulates in lane 4b+j,
+// register i.  One MFMA per input channel: 2 x ds_read_b128 + 4 MFMAs per (tap, 4 channels), no VALU in the loop, no
+// scalar-load latency (the VALU form above waits lgkmcnt(0) on every weight fetch).
+template <int NCO>
+__global__ __launch_bounds__(256, 2) void conv_small_mfma_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[S_HH * S_RS + 9 * 8 * 16];
+    float* const wl = lds + S_HH * S_RS;          // [tap][octet s*2+h][cout 4][e 4]
+    const int tid = threadIdx.x;
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int b = bx / p.tiles_y;
+    const int oy0 = ty * S_TH, ox0 = tx * S_TW;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+
+    const int q = tid & 7, pl = tid >> 3;
+    int soff[S_NPASS];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int i = 0; i < S_NPASS; ++i) {
+        const int hp = i * 32 + pl;
+        const int hy = hp / S_HW, hx = hp - hy * S_HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool ok = hp < S_NPIX && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+        soff[i] = ok ? ((b * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups)) : 0;
+        vmask |= ok ? (1u << i) : 0u;
+    }
+    f32x4 pre[S_NPASS];
+    f32x4 gsc, gsh, wpre[2];
+    bool cvalid;
+    auto issue_loads = [&](int chunk) {
+        const int s = chunk >= p.nchunk0;
+        const int cl = (s ? chunk - p.nchunk0 : chunk) * S_KC + q * 4;
+        const int cs = p.csrc[s];
+        cvalid = cl < cs;
+        const float* __restrict__ base = p.src[s] + (cvalid ? cl : 0);
+#pragma unroll
+        for (int i = 0; i < S_NPASS; ++i) pre[i] = *reinterpret_cast<const f32x4*>(base + (size_t)soff[i] * cs);
+        if (p.gn) {
+            const int cg = cvalid ? (s ? p.csrc[0] : 0) + cl : 0;
+            gsc = *reinterpret_cast<const f32x4*>(p.gscale + (size_t)b * p.ctot + cg);
+            gsh = *reinterpret_cast<const f32x4*>(p.gshift + (size_t)b * p.ctot + cg);
+        }
+        // this chunk's weights out of the MFMA-packed image of output tile 0: group (tap, s) = 1 KiB; the 64 bytes at lane 0
+        // (h = 0) and at lane 32 (h = 1) hold W[n = 0..3][4 channels]: 288 float4 per chunk, threads 0..255 (+ 0..31 again)
+        const float* __restrict__ wc = p.w + (size_t)chunk * (9 * 1024);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int v = tid + r * 256;                    // float4 index: ((tap*4 + s)*2 + h)*4 + n
+            const int n = v & 3, h = (v >> 2) & 1, ts = v >> 3;
+            wpre[r] = v < 288 ? *reinterpret_cast<const f32x4*>(wc + ts * 256 + h * 128 + n * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto write_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < S_NPASS; ++i) {
+            const int hp = i * 32 + pl;
+            const int hy = hp / S_HW, hx = hp - hy * S_HW;
+            f32x4 v = pre[i];
+            const bool ok = cvalid && ((vmask >> i) & 1u);
+            if (p.gn) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], gsc[e], gsh[e]);
+            }
+            if (p.silu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f<false>(v[e]);
+            }
+            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (hp < S_NPIX) *reinterpret_cast<f32x4*>(&lds[hy * S_RS + hx * S_PS + q * 4]) = v;
+        }
+        *reinterpret_cast<f32x4*>(&wl[tid * 4]) = wpre[0];
+        if (tid < 32) *reinterpret_cast<f32x4*>(&wl[(tid + 256) * 4]) = wpre[1];
+    };
+
+    const int py = tid >> 5, px = tid & 31;
+    const int a_base = py * S_RS + px * S_PS;
+    const int w_base = (tid & 3) * 4;               // this lane's cout column of every [4][4] weight block
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};               // acc[i] = out[pixel 4*(lane/4) + i][cout lane & 3]
+
+    issue_loads(0);
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        write_lds();
+        __syncthreads();
+        if (chunk + 1 < p.nchunks) issue_loads(chunk + 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {           // o = s*2 + h: channels 4*o .. 4*o+3 of the chunk
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&lds[a_base + ky * S_RS + kx * S_PS + o * 4]);
+                const f32x4 w = *reinterpret_cast<const f32x4*>(&wl[(tap * 8 + o) * 16 + w_base]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], w[e], acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // lane (block blk = lane / 4, column j = lane & 3), register i -> pixel 4*blk + i of this wave's 64 pixels, cout j
+    const int j = tid & 3;
+    if (j < NCO && j < p.Cout) {
+        float add = p.bias ? p.bias[j] : 0.f;
+        if (p.temb) add += p.temb[(size_t)b * p.temb_ld + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pix_in_wg = (tid & ~63) + ((tid & 63) >> 2) * 4 + i;      // = wave * 64 + 4*blk + i
+            const int oy = oy0 + (pix_in_wg >> 5), ox = ox0 + (pix_in_wg & 31);
+            if (oy < p.Hout && ox < p.Wout) {
+                const size_t pix = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+                float v = acc[i] + add;
+                if (p.residual) v += p.residual[pix * p.Cout + j];
+                p.out[pix * p.out_ld + j] = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
-int conv_dispatch_small(const ConvParams& p, hipStream_t stream) {
+int conv_dispatch_small(const ConvParams& p, hipStream_t stream, bool valu_form) {
     dim3 grid(p.tiles_x * p.tiles_y * p.B, 1);
-    if (p.Cout <= 3) hipLaunchKernelGGL(conv_small_kernel<3>, grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(conv_small_kernel<4>, grid, dim3(256), 0, stream, p);
+    if (valu_form) {
+        if (p.Cout <= 3) hipLaunchKernelGGL(conv_small_kernel<3>, grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(conv_small_kernel<4>, grid, dim3(256), 0, stream, p);
+    } else {
+        if (p.Cout <= 3) hipLaunchKernelGGL(conv_small_mfma_kernel<3>, grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(conv_small_mfma_kernel<4>, grid, dim3(256), 0, stream, p);
+    }
     return check_launch();
 }
 

@@ -68,7 +68,7 @@ def tiles_for(k, s, wout=0, cout=999):
         return (-1, 0, 1, 2) + ((5, 6) if wout < 32 else ())
     if s == 2:
         return (-1, 3, 4, 5)
-    return (-1, 0, 1, 2, 5, 6) + ((8,) if wout >= 32 and cout <= 4 else ()) + ((7, 31, 35) if wout >= 32 else ())     # 7 = Winograd (8-wave form); experimental ids: 31 = 4-wave form, 35 = persistent 4-wave form
+    return (-1, 0, 1, 2, 5, 6) + ((8, 9) if wout >= 32 and cout <= 4 else ()) + ((7, 31, 35) if wout >= 32 else ())     # 7 = Winograd (8-wave form); experimental ids: 31 = 4-wave form, 35 = persistent 4-wave form
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
