@@ -98,6 +98,7 @@ Tile tile_of(int wcfg) {
         case WCFG_S32: return {wcfg, 32, 32, 1};
         case WCFG_S64: return {wcfg, 64, 32, 1};
         case WCFG_WINO: return {wcfg, 128, 128, 2};   // (wm = 2: the 8-wave kernel writes two GroupNorm slots per tile)
+        case WCFG_CIN8: return {wcfg, 128, 128, 1};    // 128x128 tile that multiplies only the first 8 channels of the chunk
         case WCFG_SMALL: return {wcfg, 256, 4, 1};     // 8 x 32 pixels, cout <= 4 (4x4x1 MFMA form)
         case WCFG_SMALL_VALU: return {wcfg, 256, 4, 1};   // same tile, vector-ALU form (scalar-cache weights)
         default: return {-1, 0, 0, 0};
@@ -112,6 +113,12 @@ bool wino_ok(const cdx_conv_args* a) {
 // cout <= 4 (conv_out): the vector-ALU kernel of conv_small.hip (no GroupNorm sums of the output: nothing normalises it)
 bool small_ok(const cdx_conv_args* a) {
     return a->ksize == 3 && a->stride == 1 && a->cout <= 4 && a->wout >= 32 && a->stats_out == nullptr;
+}
+
+// at most 8 input channels in ONE source (conv_in: x_t | cond | pad): the direct kernel without the 24 zero channels of its
+// only chunk -- 36 MFMA k-steps per output block where the Winograd kernel spends a whole 128-MFMA chunk
+bool cin8_ok(const cdx_conv_args* a) {
+    return a->ksize == 3 && a->stride == 1 && a->c0 <= 8 && a->c1 == 0 && a->wout >= 32 && a->cout > 4;
 }
 
 // Tile-shape heuristic.  Depends on the LAYER shape only, never on the batch: a different tile changes the
@@ -130,6 +137,7 @@ Tile select_tile(const cdx_conv_args* a) {
     }
     if (a->ksize == 3) {
         if (hw <= kSplitKMaxPixels) t = tile_of(a->stride == 1 && hw >= 256 ? WCFG_S64 : WCFG_S32);
+        else if (cin8_ok(a)) t = tile_of(WCFG_CIN8);
         else if (wino_ok(a) && a->cout >= 96) t = tile_of(WCFG_WINO);
         else if (small_ok(a)) t = tile_of(WCFG_SMALL);
     }
@@ -140,6 +148,7 @@ bool tile_allowed(const cdx_conv_args* a, int wcfg) {
     if (a->ksize == 1) return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1 || ((wcfg == WCFG_S32 || wcfg == WCFG_S64) && a->wout < 32);
     if (a->stride == 2) return wcfg == WCFG_1x4x2 || wcfg == WCFG_2x2x1 || wcfg == WCFG_S32;
     if (wcfg == WCFG_WINO) return wino_ok(a);
+    if (wcfg == WCFG_CIN8) return cin8_ok(a);
     if (wcfg == WCFG_SMALL || wcfg == WCFG_SMALL_VALU) return small_ok(a);
     return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1 || wcfg == WCFG_S32 || wcfg == WCFG_S64;
 }

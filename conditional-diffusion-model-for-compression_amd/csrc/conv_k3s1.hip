@@ -23,6 +23,7 @@ namespace cdx {
     CDX_CONV_CASE(KS, ST, 5, 2, 4, 1, 1) \
     CDX_CONV_CASE(KS, ST, 5, 5, 1, 1, 1, 4, 3) \
     CDX_CONV_CASE(KS, ST, 5, 6, 1, 1, 2, 4, 3) \
+    CDX_CONV_CASE(KS, ST, 5, 10, 1, 4, 4, 1, 3, OPT_OCC2 | OPT_CIN8) \
 
 int conv_dispatch_k3s1(int logtw, int wcfg, const ConvParams& p, hipStream_t stream) {
     CDX_CONV_DISPATCH_BODY(3, 1)

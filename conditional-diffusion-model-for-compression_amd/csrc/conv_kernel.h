@@ -55,7 +55,9 @@ enum { OPT_SPLIT_LDS_READS = 1,  // hide the 16-B alignment: 2 x ds_read2_b32 pe
        // timing-only ablations (WRONG RESULTS; conv_exp.hip only):
        OPT_ABL_NO_STAGE = 16,    // chunks after the first skip the global loads + LDS writes (barriers stay)
        OPT_ABL_NO_EPILOGUE = 32, // no output stores / residual reads (one store keeps the accumulators live)
-       OPT_ABL_ONE_WG = 64 };    // declare 96 KiB of LDS: one workgroup per CU
+       OPT_ABL_ONE_WG = 64,      // declare 96 KiB of LDS: one workgroup per CU
+       OPT_CIN8 = 256 };         // the layer has at most 8 input channels (conv_in): only the first 8-channel group of a
+                                 // (chunk, tap) carries data, the other three (zeros) are not multiplied
 template <int KS_, int STRIDE_, int LOGTW_, int WM_, int WN_, int MT_, int WK_ = 1, int PF_ = 1, int OPT_ = 0>
 struct ConvCfg {
     static constexpr int KS = KS_, STRIDE = STRIDE_, LOGTW = LOGTW_, WM = WM_, WN = WN_, MT = MT_, WK = WK_, PF = PF_, OPT = OPT_;
@@ -67,7 +69,7 @@ struct ConvCfg {
     static constexpr int RPM = 32 / TW;  // output rows per 32-pixel MFMA tile
     static constexpr int HH = (TH - 1) * STRIDE + KS, HW = (TW - 1) * STRIDE + KS;
     static constexpr int RS = ((HW * PS + 63) / 64) * 64;
-    static constexpr int G = 4 / WK;                      // 8-channel groups per (chunk, tap) per wave
+    static constexpr int G = (OPT_ & 256) ? 1 : 4 / WK;   // 8-channel groups per (chunk, tap) per wave (OPT_CIN8: the first only)
     static constexpr int GPC = KS * KS * G;               // groups per chunk per wave
     static constexpr int RED_FLOATS = WK > 1 ? 4 * MT * 16 * 64 : 0;   // split-K reduction image
     static constexpr int LDS_FLOATS = HH * RS > RED_FLOATS ? HH * RS : RED_FLOATS;
@@ -396,7 +398,7 @@ inline int conv_launch(const ConvParams& p, hipStream_t stream) {
 // tile-shape ids used by the dispatcher (WM x WN x MT [x WK]); the S* shapes split K over the 4 waves
 // and exist for the low-resolution levels, where the big tiles would leave most CUs idle.
 enum { WCFG_1x4x4 = 0, WCFG_2x2x2 = 1, WCFG_4x1x1 = 2, WCFG_1x4x2 = 3, WCFG_2x2x1 = 4, WCFG_S32 = 5, WCFG_S64 = 6,
-       WCFG_WINO = 7, WCFG_SMALL = 8, WCFG_SMALL_VALU = 9 };
+       WCFG_WINO = 7, WCFG_SMALL = 8, WCFG_SMALL_VALU = 9, WCFG_CIN8 = 10 };
 int conv_dispatch_small(const ConvParams& p, hipStream_t stream, bool valu_form);   // conv_small.hip: 3x3 stride 1, cout <= 4
 
 int conv_dispatch_k3s1(int logtw, int wcfg, const ConvParams& p, hipStream_t stream);

@@ -103,7 +103,8 @@ enum {
     CDX_TILE_S64x32 = 6,
     CDX_TILE_WINO = 7,    /* Winograd F(2x2,3x3), 128 pixels x 128 channels, needs wpacked_wino */
     CDX_TILE_SMALL = 8,   /* 3x3 stride 1, cout <= 4, width >= 32: 4x4x1-MFMA kernel, 256 pixels  */
-    CDX_TILE_SMALL_VALU = 9 /* the same tile on the vector ALU (weights through the scalar cache)   */
+    CDX_TILE_SMALL_VALU = 9, /* the same tile on the vector ALU (weights through the scalar cache)  */
+    CDX_TILE_CIN8 = 10    /* 3x3 stride 1, at most 8 input channels (conv_in): 128x128, first channel group only */
 };
 int cdx_conv_select_tile(const cdx_conv_args* a);
 int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void* workspace, size_t workspace_bytes, cdx_stream_t stream);

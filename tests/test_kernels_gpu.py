@@ -47,6 +47,8 @@ CONV_CASES = [
     (2, 128, 64, 8, 8, 3, 1, False),       # TW=8, 2x2x2 wave layout
     (3, 32, 32, 4, 4, 3, 1, False),        # TW=4, 4x1x1 layout, image smaller than a tile
     (1, 8, 48, 40, 24, 3, 1, False),       # Cin < chunk (zero-filled), ragged H and W
+    (2, 8, 128, 36, 40, 3, 1, False),      # conv_in shape: 8 input channels, first-group-only tile (id 10) by default
+    (1, 4, 96, 32, 64, 3, 1, False),       # 4 input channels
     (2, 32, 3, 32, 32, 3, 1, False),       # conv_out shape: cout = 3 (vector-ALU kernel, tile 8)
     (1, 72, 4, 21, 45, 3, 1, False),       # cout = 4, ragged, Cin not a multiple of the chunk
     (1, 64, 2, 16, 20, 3, 1, True),        # cout = 2 with the fused upsample (40 wide)
@@ -61,14 +63,14 @@ CONV_CASES = [
 ]
 
 
-def tiles_for(k, s, wout=0, cout=999):
+def tiles_for(k, s, wout=0, cout=999, cin=999):
     """Every tile shape built for this ksize / stride (include/cdx.h CDX_TILE_*), plus -1 = the library's pick.
     Tile 7 = Winograd F(2x2,3x3) (3x3 stride 1, output width >= 32)."""
     if k == 1:
         return (-1, 0, 1, 2) + ((5, 6) if wout < 32 else ())
     if s == 2:
         return (-1, 3, 4, 5)
-    return (-1, 0, 1, 2, 5, 6) + ((8, 9) if wout >= 32 and cout <= 4 else ()) + ((7, 31, 35) if wout >= 32 else ())     # 7 = Winograd (8-wave form); experimental ids: 31 = 4-wave form, 35 = persistent 4-wave form
+    return (-1, 0, 1, 2, 5, 6) + ((8, 9) if wout >= 32 and cout <= 4 else ()) + ((10,) if wout >= 32 and cin <= 8 and cout > 4 else ()) + ((7, 31, 35) if wout >= 32 else ())     # 7 = Winograd (8-wave form); experimental ids: 31 = 4-wave form, 35 = persistent 4-wave form
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
@@ -81,7 +83,7 @@ def test_conv_plain(cdx_mod, case):
     want = F.conv2d(xin, w.double(), bias.double(), stride=s, padding=k // 2)
     pc = cdx_mod.ops.PackedConv(w.numpy(), bias.numpy(), ci)
     xd = nhwc(x)
-    for tile in tiles_for(k, s, want.shape[-1], co):
+    for tile in tiles_for(k, s, want.shape[-1], co, ci):
         got = nchw(cdx_mod.ops.conv(pc, xd, stride=s, upsample=up, tile=tile))
         assert got.shape == want.shape
         close(got, want, 4e-6 if tile in (7, 31, 35) else 2e-6, f"conv tile {tile}")
