@@ -76,6 +76,9 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned vo
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// WARNING (tools/microbench/store_hazard.hip): with a non-constant `soff` hipcc (ROCm 7.2) inserts NO
+// wait state between this store and a following VALU write to one of v's registers, and gfx950 then stores the NEW
+// value in some lanes.  Callers must not let v's registers be rewritten before the wave ends (conv_wino.h epilogue).
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
