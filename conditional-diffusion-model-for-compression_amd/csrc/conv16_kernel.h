@@ -260,10 +260,6 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     // 4x wider memory instructions than the accumulator layout allows.  GroupNorm sums are reduced in that layout.
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     auto epilogue = [&](auto has_res, auto has_stats, auto out32) __attribute__((always_inline)) {
-        // RULE (conv_wino.h): registers read by a 16-byte store are not written again before the wave
-        // ends.  (The 8-byte fp16 stores are outside the > 64-bit store-data class the corruption was observed in, and
-        // holding their vectors costs a wave of occupancy: 15.4 -> 16.3 ms per cfg5 step.)
-        f32x4 ov32[decltype(out32)::value ? MT : 1][4];
         f16x4 rv[MT][4];
         if constexpr (decltype(has_res)::value) {      // one batch of 8-byte loads (a load in the last chunk instead
 #pragma unroll                                          // would queue the weight ring behind HBM misses: vmcnt is in-order)
@@ -290,8 +286,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
                         for (int c = 0; c < 4; ++c) x[c] += (float)rv[t][k][c];
                     }
                     if constexpr (decltype(out32)::value) {
-                        ov32[t][k] = f32x4{x[0], x[1], x[2], x[3]};
-                        *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + pix * p.out_ld + cq) = ov32[t][k];
+                        *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + pix * p.out_ld + cq) = f32x4{x[0], x[1], x[2], x[3]};
                     } else {
                         *reinterpret_cast<f16x4*>(static_cast<_Float16*>(p.out) + pix * p.out_ld + cq) =
                             f16x4{(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
@@ -306,10 +301,6 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
                     }
                 }
             }
-        }
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            if constexpr (decltype(out32)::value) asm volatile("" :: "v"(ov32[t][0]), "v"(ov32[t][1]), "v"(ov32[t][2]), "v"(ov32[t][3]));
         }
     };
     using T_ = std::true_type;

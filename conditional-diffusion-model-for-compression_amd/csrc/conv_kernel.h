@@ -312,13 +312,6 @@ __global__ __launch_bounds__(256, (C::OPT & OPT_OCC2) ? 2 : 3) void conv_kernel(
         return;      // (GroupNorm sums are only requested for multiple-of-4 channel counts)
     }
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    // RULE (conv_wino.h): a register that a 16-byte store reads is not written again before the wave
-    // ends -- every stored vector gets its own registers, kept allocated by the empty asm after the loops.
-    f32x4 ov[MT][4];
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ov[t][k] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto epilogue = [&](auto has_res, auto has_stats) __attribute__((always_inline)) {
         f32x4 rv[MT][4];
         if constexpr (decltype(has_res)::value) {
@@ -345,8 +338,9 @@ __global__ __launch_bounds__(256, (C::OPT & OPT_OCC2) ? 2 : 3) void conv_kernel(
 #pragma unroll
                         for (int c = 0; c < 4; ++c) x[c] += rv[t][k][c];
                     }
-                    ov[t][k] = f32x4{x[0], x[1], x[2], x[3]};
-                    *reinterpret_cast<f32x4*>(p.out + pix * p.out_ld + cq) = ov[t][k];
+                    // (a global store: hipcc's hazard recogniser keeps a following write of these registers one wait state
+                    // away -- the exemption that bit the Winograd kernel is for buffer stores with an SGPR soffset only)
+                    *reinterpret_cast<f32x4*>(p.out + pix * p.out_ld + cq) = f32x4{x[0], x[1], x[2], x[3]};
                     if constexpr (decltype(has_stats)::value) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
@@ -363,8 +357,6 @@ __global__ __launch_bounds__(256, (C::OPT & OPT_OCC2) ? 2 : 3) void conv_kernel(
     using F_ = std::false_type;
     if (p.residual) { if (p.stats) epilogue(T_{}, T_{}); else epilogue(T_{}, F_{}); }
     else { if (p.stats) epilogue(F_{}, T_{}); else epilogue(F_{}, F_{}); }
-#pragma unroll
-    for (int t = 0; t < MT; ++t) asm volatile("" :: "v"(ov[t][0]), "v"(ov[t][1]), "v"(ov[t][2]), "v"(ov[t][3]));
     if (p.stats) {      // wave-uniform
 #pragma unroll
         for (int c = 0; c < 4; ++c) {      // the quad's 4 lanes and the two lane halves hold different pixels
