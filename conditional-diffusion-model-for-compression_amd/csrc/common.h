@@ -76,11 +76,13 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned vo
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-// WARNING (tools/microbench/store_hazard.hip): with a non-constant `soff` hipcc (ROCm 7.2) inserts NO
-// wait state between this store and a following VALU write to one of v's registers, and gfx950 then stores the NEW
-// value in some lanes.  Callers must not let v's registers be rewritten before the wave ends (conv_wino.h epilogue).
+// NOTE (tools/microbench/store_hazard.hip): for a buffer store whose soffset is a register hipcc
+// (ROCm 7.2) inserts NO wait state before a following VALU write to one of the data registers, and gfx950 then stores the
+// NEW value in some lanes (lanes 12-15 of every 16, last dword).  The two wait states are therefore issued here, TIED to the
+// data registers ("+v": the asm formally rewrites them), so that no later write can be scheduled in front of them.
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+    asm volatile("s_nop 1" : "+v"(v));
 }
 
 }  // namespace cdx

@@ -1092,12 +1092,8 @@ __device__ __forceinline__ void conv_wino8_body(const ConvParams& p, float* lds)
     }
 
     // ---- packed stores (quad transposes) of this wave's 8 tile-registers x 4 positions ----
-    // RULE: a register that a 16-byte store reads is never written again before the wave ends.  When the compiler was free
-    // to recycle the data registers of store i for the transpose of vector i+1, variants of this kernel returned -- in
-    // 1-15 % of launches, only from the second wave of a SIMD -- the last dword of the last lane quad of each 16-lane
-    // group of ONE store replaced by the next vector's value: the registers were re-written (ds_bpermute returns /
-    // v_cndmask) while the store still waited behind the other wave's stores.
-    // Detector: tools/flake_probe.py and test_winograd_repeatable_across_launch_sequences; DESIGN.md section 8.
+    // (buf_store4 carries its own wait states: variants of this kernel were flaky until the store-data hazard of
+    // buffer stores with an SGPR soffset was found -- DESIGN.md section 8, tools/flake_probe.py, tools/microbench/store_hazard.hip)
     int eoy0 = oy0, eox0 = ox0, elh = lh;
     asm volatile("" : "+s"(eoy0), "+s"(eox0), "+v"(elh));
     const int q4 = li & 3;
@@ -1105,11 +1101,8 @@ __device__ __forceinline__ void conv_wino8_body(const ConvParams& p, float* lds)
     const bool quad_ok = cq < p.Cout;
     const bool vec_ok = (p.out_ld & 3) == 0 && cq + 4 <= p.out_ld;
     const bool fast_store = full_tile && vec_ok && ntile * 32 + 32 <= p.Cout;      // wave-uniform
-    f32x4 ov[8];
     if (fast_store) {
         // scalar base per (kk, pos) + one per-lane offset: tile = 8*(2*wh + kk) + q4 + 4*lh -> row wh, column 8*kk + q4 + 4*lh
-        // Each store follows its transpose, but all eight vectors live in DISTINCT registers that stay allocated until the
-        // wave ends (the empty asm below reads them), so nothing can be written over a pending store's data.
         const __amdgpu_buffer_rsrc_t ro = buf_rsrc(p.out + (((size_t)b * p.Hout + eoy0 + 2 * wh) * p.Wout + eox0) * p.out_ld);
         const unsigned voff = ((unsigned)(2 * (q4 + 4 * elh)) * (unsigned)p.out_ld + (unsigned)cq) * 4u;
 #pragma unroll
@@ -1118,11 +1111,9 @@ __device__ __forceinline__ void conv_wino8_body(const ConvParams& p, float* lds)
             for (int pos = 0; pos < 4; ++pos) {
                 float x[4] = {mine[(4 * kk + 0) * 4 + pos], mine[(4 * kk + 1) * 4 + pos], mine[(4 * kk + 2) * 4 + pos], mine[(4 * kk + 3) * 4 + pos]};
                 quad_transpose(x, q4);
-                ov[kk * 4 + pos] = f32x4{x[0], x[1], x[2], x[3]};
                 const unsigned pix = (unsigned)(pos >> 1) * (unsigned)p.Wout + (unsigned)(16 * kk + (pos & 1));
-                buf_store4(ro, voff, pix * (unsigned)p.out_ld * 4u, ov[kk * 4 + pos]);
+                buf_store4(ro, voff, pix * (unsigned)p.out_ld * 4u, f32x4{x[0], x[1], x[2], x[3]});
             }
-        asm volatile("" :: "v"(ov[0]), "v"(ov[1]), "v"(ov[2]), "v"(ov[3]), "v"(ov[4]), "v"(ov[5]), "v"(ov[6]), "v"(ov[7]));
     } else {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -1132,19 +1123,17 @@ __device__ __forceinline__ void conv_wino8_body(const ConvParams& p, float* lds)
             for (int pos = 0; pos < 4; ++pos) {
                 float x[4] = {mine[(4 * kk + 0) * 4 + pos], mine[(4 * kk + 1) * 4 + pos], mine[(4 * kk + 2) * 4 + pos], mine[(4 * kk + 3) * 4 + pos]};
                 quad_transpose(x, q4);
-                ov[kk * 4 + pos] = f32x4{x[0], x[1], x[2], x[3]};
                 const int py = oy + (pos >> 1), px = ox + (pos & 1);
                 if (quad_ok && py < p.Hout && px < p.Wout) {
                     const size_t pix = ((size_t)b * p.Hout + py) * p.Wout + px;
-                    if (vec_ok) *reinterpret_cast<f32x4*>(p.out + pix * p.out_ld + cq) = ov[kk * 4 + pos];
+                    if (vec_ok) *reinterpret_cast<f32x4*>(p.out + pix * p.out_ld + cq) = f32x4{x[0], x[1], x[2], x[3]};
                     else
 #pragma unroll
                         for (int c = 0; c < 4; ++c)
-                            if (cq + c < p.Cout) p.out[pix * p.out_ld + cq + c] = ov[kk * 4 + pos][c];
+                            if (cq + c < p.Cout) p.out[pix * p.out_ld + cq + c] = x[c];
                 }
             }
         }
-        asm volatile("" :: "v"(ov[0]), "v"(ov[1]), "v"(ov[2]), "v"(ov[3]), "v"(ov[4]), "v"(ov[5]), "v"(ov[6]), "v"(ov[7]));
     }
 }
 

@@ -65,7 +65,14 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* pad_src, in
         const f32x4 v = f32x4{x[0], x[1], x[2], x[3]};
         if (MODE == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, lane * 16, s * 1024 * spread, 0);
         else if (MODE == 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, lane * 16 + s * 1024 * spread, 0, 0);
-        else *reinterpret_cast<f32x4*>(out + (size_t)(g * 8 + w) * 8 * 256 + s * 256 + lane * 4) = v;
+        else if (MODE == 2) *reinterpret_cast<f32x4*>(out + (size_t)(g * 8 + w) * 8 * 256 + s * 256 + lane * 4) = v;
+        else {      // 3: SGPR soffset, followed by wait states that are TIED to the data registers (the asm "rewrites" them, so
+                    // no later write can be scheduled in front of it)
+            f32x4 t = v;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rs, lane * 16, s * 1024 * spread, 0);
+            asm volatile("s_nop 1" : "+v"(t));
+            x[0] = t[0];      // keep the tie alive into the next iteration's registers
+        }
     }
     float keep = 0.f;
 #pragma unroll
@@ -84,14 +91,15 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 4096; ++i) h[i] = (float)(i % 97) * 0.5f;
     hipMemcpy(pad, h.data(), 4096 * 4, hipMemcpyHostToDevice);
     std::vector<float> res(n);
-  for (int mode = 0; mode < 3; ++mode) {
+  for (int mode = 0; mode < 4; ++mode) {
     long bad_launches = 0, bad_dwords = 0;
     int shown = 0;
     for (int it = 0; it < launches; ++it) {
         hipMemset(out, 0xff, n * 4);
         if (mode == 0) k<0><<<G, 512>>>(out, pad, 4096, 1);
         else if (mode == 1) k<1><<<G, 512>>>(out, pad, 4096, 1);
-        else k<2><<<G, 512>>>(out, pad, 4096, 1);
+        else if (mode == 2) k<2><<<G, 512>>>(out, pad, 4096, 1);
+        else k<3><<<G, 512>>>(out, pad, 4096, 1);
         hipMemcpy(res.data(), out, n * 4, hipMemcpyDeviceToHost);
         long bad = 0;
         for (int g = 0; g < G; ++g)
@@ -111,7 +119,7 @@ int main(int argc, char** argv) {
         bad_launches += bad != 0;
         bad_dwords += bad;
     }
-    printf("store_hazard mode %d (0 = buffer store with an SGPR soffset, 1 = buffer store with soffset 0, 2 = global store): %ld bad launches of %d, %ld bad dwords (%s)\n", mode, bad_launches, launches, bad_dwords, hipGetErrorString(hipGetLastError()));
+    printf("store_hazard mode %d (0 = buffer store with an SGPR soffset, 1 = buffer store with soffset 0, 2 = global store, 3 = mode 0 + s_nop 1 tied to the data registers): %ld bad launches of %d, %ld bad dwords (%s)\n", mode, bad_launches, launches, bad_dwords, hipGetErrorString(hipGetLastError()));
   }
     return 0;
 }
