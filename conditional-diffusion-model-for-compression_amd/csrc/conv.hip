@@ -187,7 +187,12 @@ extern "C" int cdx_conv_select_tile(const cdx_conv_args* a) {
 
 extern "C" int32_t cdx_conv_stats_slots(const cdx_conv_args* a) {
     if (validate(a)) return 0;
-    const Tile t = select_tile(a);
+    // the question is asked BEFORE the caller has a buffer to put into stats_out: answer for the launch WITH sums
+    // (a layer with cout <= 4 runs the matrix-pipe tile then, not the small kernels, which produce none)
+    cdx_conv_args with_stats = *a;
+    if (!with_stats.stats_out) with_stats.stats_out = reinterpret_cast<double*>(uintptr_t(16));
+    if (validate(&with_stats)) return 0;
+    const Tile t = select_tile(&with_stats);
     const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : a->wout >= 8 ? 3 : 2;
     const int tw = 1 << logtw, th = t.bm / tw;
     return ceil_div(a->wout, tw) * ceil_div(a->hout, th) * t.wm;

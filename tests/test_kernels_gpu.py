@@ -126,7 +126,8 @@ def test_conv_fused_gn_silu_concat_temb_residual(cdx_mod, B, c0, c1, co, H, W, g
 
 @pytest.mark.parametrize("B,ci,c_a,c_b,H,W,k,s,tile", [(2, 32, 64, 32, 32, 32, 3, 1, -1), (1, 64, 128, 0, 16, 16, 3, 1, -1), (2, 32, 96, 64, 8, 8, 1, 1, -1),
                                                         (2, 32, 64, 0, 40, 24, 3, 2, -1), (3, 32, 32, 32, 4, 4, 3, 1, -1), (1, 32, 160, 0, 64, 64, 3, 1, -1),
-                                                        (2, 32, 160, 128, 40, 72, 3, 1, -1), (3, 64, 128, 0, 8, 32, 3, 1, -1)])    # last two: Winograd kernel, ragged tiles
+                                                        (2, 32, 160, 128, 40, 72, 3, 1, -1), (3, 64, 128, 0, 8, 32, 3, 1, -1),     # Winograd kernel, ragged tiles
+                                                        (1, 32, 4, 0, 34, 42, 3, 1, -1)])       # cout = 4 WITH sums: not the small kernels (found by tools/fuzz_conv.py)
 def test_conv_epilogue_stats_match_standalone_gn(cdx_mod, B, ci, c_a, c_b, H, W, k, s, tile):
     """GroupNorm statistics accumulated in the producing convs' epilogues (one or two producers = concat) give the
     same scale/shift as the standalone pass over the stored tensors, and as float64 torch."""
@@ -143,9 +144,10 @@ def test_conv_epilogue_stats_match_standalone_gn(cdx_mod, B, ci, c_a, c_b, H, W,
     gamma, beta = (1 + 0.2 * rnd(C, seed=65)).cuda(), (0.3 * rnd(C, seed=66)).cuda()
     hw = outs[0].shape[1] * outs[0].shape[2]
     o1 = outs[1] if c_b else None
-    sc_f, sh_f, m_f, r_f = ops.gn_finalize(stats[0], stats[1] if c_b else None, hw, gamma, beta, 32, want_moments=True)
-    sc_s, sh_s, m_s, r_s = ops.gn_stats(outs[0], o1, gamma, beta, 32, want_moments=True)
-    xc = torch.cat([nchw(o) for o in outs], 1).double().reshape(B, 32, -1)
+    G = 32 if C % 32 == 0 else 4
+    sc_f, sh_f, m_f, r_f = ops.gn_finalize(stats[0], stats[1] if c_b else None, hw, gamma, beta, G, want_moments=True)
+    sc_s, sh_s, m_s, r_s = ops.gn_stats(outs[0], o1, gamma, beta, G, want_moments=True)
+    xc = torch.cat([nchw(o) for o in outs], 1).double().reshape(B, G, -1)
     close(m_f.cpu(), xc.mean(-1), 1e-6, "fused mean")
     close(r_f.cpu(), (xc.var(-1, unbiased=False) + 1e-5).rsqrt(), 2e-6, "fused rstd")
     assert torch.allclose(sc_f, sc_s, rtol=1e-6, atol=1e-7) and torch.allclose(sh_f, sh_s, rtol=1e-5, atol=1e-6)
