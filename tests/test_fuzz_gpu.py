@@ -1,0 +1,20 @@
+"""Randomised parity sweeps (tools/fuzz_conv.py, tools/fuzz_conv16.py) as part of the GPU suite: random layer shapes and
+fusion flags through the library's own tile choice, against float64 torch on the CPU.  The fp32 sweep found the
+`cdx_conv_stats_slots` inconsistency for cout <= 4 in round 1."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("tool,cases,seed", [("fuzz_conv.py", 150, 11), ("fuzz_conv16.py", 100, 12)])
+def test_randomised_conv_sweep(lib, tool, cases, seed):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(cases), str(seed)],
+                       capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert f" 0 bad of {cases}" in r.stdout, tail
