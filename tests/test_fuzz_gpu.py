@@ -1,4 +1,4 @@
-"""Randomised parity sweeps (tools/fuzz_conv.py, tools/fuzz_conv16.py) as part of the GPU suite: random layer shapes and
+"""Randomised parity sweeps (tools/fuzz_conv.py, tools/fuzz_conv16.py, tools/fuzz_attn.py) as part of the GPU suite: random layer shapes and
 fusion flags through the library's own tile choice, against float64 torch on the CPU.  The fp32 sweep found the
 `cdx_conv_stats_slots` inconsistency for cout <= 4 in round 1."""
 import os
@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,cases,seed", [("fuzz_conv.py", 150, 11), ("fuzz_conv16.py", 100, 12)])
+@pytest.mark.parametrize("tool,cases,seed", [("fuzz_conv.py", 150, 11), ("fuzz_conv16.py", 100, 12), ("fuzz_attn.py", 80, 13)])
 def test_randomised_conv_sweep(lib, tool, cases, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(cases), str(seed)],
                        capture_output=True, text=True, timeout=900)
