@@ -11,9 +11,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,cases,seed", [("fuzz_conv.py", 150, 11), ("fuzz_conv16.py", 100, 12), ("fuzz_attn.py", 80, 13)])
+@pytest.mark.parametrize("tool,cases,seed", [("fuzz_conv.py", 150, 11), ("fuzz_conv16.py", 100, 12), ("fuzz_attn.py", 80, 13), ("fuzz_unet.py", 8, 14)])
 def test_randomised_conv_sweep(lib, tool, cases, seed):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(cases), str(seed)],
+    path = os.path.join(ROOT, "tests" if tool == "fuzz_unet.py" else "tools", tool)
+    r = subprocess.run([sys.executable, path, str(cases), str(seed)],
                        capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
