@@ -141,6 +141,22 @@ def test_sampler_winograd_path_vs_live_oracle(cdx_mod, record):
     assert psnr(got, want) >= 80.0 and abs(psnr(got, tgt) - psnr(want, tgt)) <= 0.01
 
 
+def test_benchmark_config_full_size_vs_live_oracle(cdx_mod, record):
+    """BASELINE.json configs[1] itself -- 256x256, the 113.7 M-parameter 128-ch UNet with bench.py's weights (seed 0) -- one
+    image, 3 DDIM steps, against the oracle run on this box's CPU (~1 s per step): both PSNR gates at the size the
+    headline number is measured on, through every kernel / tile kind that bench.py times."""
+    import oracle
+    cfg, _ = cdx_mod.named_config("cfg2")
+    params = cdx_mod.init_params(cfg, seed=0)
+    sb = cdx_mod.synthetic_batch(cfg, 0, 0, 1)
+    cond, tgt = torch.from_numpy(sb["cond"]), torch.from_numpy(sb["target"])
+    got = cdx_mod.Sampler(cdx_mod.UNet(cfg, params)).sample(cond.cuda(), 3, seed=0).cpu()
+    want = oracle.sample_ref(cfg, params, cond, 3, seed=0)
+    record("sampler_cfg2_full_size", psnr_hip_vs_oracle=psnr(got, want), dpsnr=abs(psnr(got, tgt) - psnr(want, tgt)),
+           max_err=(got - want).abs().max().item())
+    assert psnr(got, want) >= 80.0 and abs(psnr(got, tgt) - psnr(want, tgt)) <= 0.01
+
+
 def test_sampler_ddpm_golden(cdx_mod, record):
     """Ancestral sampling (fresh device noise every step) against the committed oracle output."""
     g = np.load(os.path.join(GOLD, "tiny_ddpm.npz"))
