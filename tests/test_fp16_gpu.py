@@ -155,3 +155,18 @@ def test_fp16_sampler_vs_fp32_oracle(cdx_mod, record):
     want, tgt = torch.from_numpy(g["x0"]), torch.from_numpy(sb["target"])
     record("fp16_sampler_cfg1", psnr_fp16_vs_oracle=psnr(got, want), dpsnr=abs(psnr(got, tgt) - psnr(want, tgt)))
     assert psnr(got, want) >= 45.0 and abs(psnr(got, tgt) - psnr(want, tgt)) <= 0.01
+
+
+def test_fp16_tile_config_full_size_vs_fp32_oracle(cdx_mod, record):
+    """BASELINE.json configs[4]'s unit of work -- one 256x256 tile through the fp16-storage 128-ch UNet (bench.py's
+    weights) -- 3 DDIM steps against the float32 oracle run on this box's CPU: the fp16 tolerance stated above."""
+    import oracle
+    cfg16, _ = cdx_mod.named_config("cfg5")
+    cfg32 = dict(cfg16, dtype="fp32")
+    params = cdx_mod.init_params(cfg32, seed=0)
+    sb = cdx_mod.synthetic_batch(cfg32, 0, 0, 1)
+    cond, tgt = torch.from_numpy(sb["cond"]), torch.from_numpy(sb["target"])
+    got = cdx_mod.Sampler(cdx_mod.UNet(cfg16, params)).sample(cond.cuda(), 3, seed=0).cpu()
+    want = oracle.sample_ref(cfg32, params, cond, 3, seed=0)
+    record("fp16_sampler_cfg5_tile_full_size", psnr_fp16_vs_oracle=psnr(got, want), dpsnr=abs(psnr(got, tgt) - psnr(want, tgt)))
+    assert psnr(got, want) >= 45.0 and abs(psnr(got, tgt) - psnr(want, tgt)) <= 0.01
