@@ -1,7 +1,12 @@
 // U1: small-M linear (timestep-embedding MLP and the per-ResBlock temb projections, all ResBlocks in
 // one call).  out[m][n] = sum_k act(x[m][k]) * w[n][k] + bias[n], M <= 64.
-// x (with the optional SiLU applied once) is staged in LDS; each wave owns output columns, lanes split
-// K with float4 loads of the weight row (coalesced, each weight read once), wave-reduced by shuffles.
+// x (with the optional SiLU applied once) is staged in LDS.  A LANE owns one output column (64 columns per workgroup),
+// the 4 waves split K into quarters, every x value is a broadcast LDS read shared by the 64 columns, and the only
+// reduction is the fixed-order sum of the four K quarters through LDS at the end.  Weight rows are read 16 bytes per
+// lane (a 128-byte line serves 8 consecutive steps from L1/L2).  Measured on the 16 x 512 x 8704 projection call
+// (weights 17.8 MB = 4 us of HBM): one column per WAVE with 16 x 6 shuffle steps per column 57 us -> this form 27 us
+// (rows split over the waves instead of K, no reduction at all: 43 us -- the kernel is bound by how many weight bytes
+// are in flight, and the K split quadruples the waves per column block).
 // No reference file exists to cite (reference snapshot is empty); semantics = torch F.linear.
 #include "common.h"
 
@@ -10,14 +15,15 @@ using namespace cdx;
 namespace {
 
 constexpr int kMB = 16;            // rows accumulated per pass
-constexpr int kColsPerWave = 8;
-constexpr int kMaxXFloats = 16384; // 64 KiB of LDS
+constexpr int kMaxXFloats = 16384; // 64 KiB of LDS for x (+ 16 KiB for the reduction)
 
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ w,
                                                      const float* __restrict__ bias, int M, int N, int K, int silu_in,
                                                      float* __restrict__ out, int out_ld) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];   // [M][K]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // xs[M][K], then red[4][kMB][64]
+    float* xs = smem;
+    float* red = smem + (size_t)M * K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid * 4; i < M * K; i += 1024) {
         const int m = i / K, k = i - m * K;
         f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)m * x_ld + k);
@@ -28,32 +34,39 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
         *reinterpret_cast<f32x4*>(xs + i) = v;
     }
     __syncthreads();
-    const int n0 = (blockIdx.x * 4 + wave) * kColsPerWave;
-    for (int n = n0; n < min(N, n0 + kColsPerWave); ++n) {
-        const float* __restrict__ wr = w + (size_t)n * K;
-        for (int m0 = 0; m0 < M; m0 += kMB) {
-            float acc[kMB];
+    const int n = blockIdx.x * 64 + lane;
+    const bool nok = n < N;
+    const float* __restrict__ wr = w + (size_t)(nok ? n : 0) * K;
+    // this wave's quarter of K (multiples of 4)
+    const int kq = ((K / 4 + 3) / 4) * 4;
+    const int k0 = wave * kq, k1 = min(K, k0 + kq);
+    for (int m0 = 0; m0 < M; m0 += kMB) {
+        float acc[kMB];
 #pragma unroll
-            for (int j = 0; j < kMB; ++j) acc[j] = 0.f;
-            for (int k = lane * 4; k < K; k += 256) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
-#pragma unroll
-                for (int j = 0; j < kMB; ++j) {
-                    if (m0 + j < M) {
-                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + (size_t)(m0 + j) * K + k);
-                        acc[j] = fmaf(wv[0], xv[0], acc[j]);
-                        acc[j] = fmaf(wv[1], xv[1], acc[j]);
-                        acc[j] = fmaf(wv[2], xv[2], acc[j]);
-                        acc[j] = fmaf(wv[3], xv[3], acc[j]);
-                    }
-                }
-            }
+        for (int j = 0; j < kMB; ++j) acc[j] = 0.f;
+        for (int k = k0; k < k1; k += 4) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
 #pragma unroll
             for (int j = 0; j < kMB; ++j) {
-                float v = acc[j];
+                if (m0 + j < M) {      // wave-uniform
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + (size_t)(m0 + j) * K + k);   // broadcast
+                    acc[j] = fmaf(wv[0], xv[0], acc[j]);
+                    acc[j] = fmaf(wv[1], xv[1], acc[j]);
+                    acc[j] = fmaf(wv[2], xv[2], acc[j]);
+                    acc[j] = fmaf(wv[3], xv[3], acc[j]);
+                }
+            }
+        }
+        __syncthreads();               // (second pass: the previous pass's partials have been consumed)
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-                if (lane == 0 && m0 + j < M) out[(size_t)(m0 + j) * out_ld + n] = v + (bias ? bias[n] : 0.f);
+        for (int j = 0; j < kMB; ++j) red[(wave * kMB + j) * 64 + lane] = acc[j];
+        __syncthreads();
+        // rows of this pass are split over the 4 waves for the final sum (fixed order: quarter 0, 1, 2, 3)
+        for (int j = wave; j < kMB; j += 4) {
+            if (m0 + j < M && nok) {
+                const float v = ((red[(0 * kMB + j) * 64 + lane] + red[(1 * kMB + j) * 64 + lane]) + red[(2 * kMB + j) * 64 + lane]) +
+                                red[(3 * kMB + j) * 64 + lane];
+                out[(size_t)(m0 + j) * out_ld + n] = v + (bias ? bias[n] : 0.f);
             }
         }
     }
@@ -69,9 +82,12 @@ extern "C" int cdx_linear_f32(const cdx_linear_args* a, void*, size_t, cdx_strea
     CDX_REQUIRE(a->x_ld >= a->k && (a->x_ld % 4) == 0 && a->out_ld >= a->n);
     CDX_REQUIRE(aligned16(a->x) && aligned16(a->w));
     if ((int64_t)a->m * a->k > kMaxXFloats) return CDX_ENOTSUP;
-    const int cols_per_wg = 4 * kColsPerWave;
-    hipLaunchKernelGGL(linear_kernel, dim3((a->n + cols_per_wg - 1) / cols_per_wg), dim3(256),
-                       (size_t)a->m * a->k * sizeof(float), static_cast<hipStream_t>(stream), a->x, a->x_ld, a->w,
+    const size_t lds_bytes = ((size_t)a->m * a->k + 4 * kMB * 64) * sizeof(float);      // <= 80 KiB
+    if (lds_bytes > 48 * 1024 &&      // more dynamic LDS than the default allowance: declare it (idempotent, no sync)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+        return CDX_ELAUNCH;
+    hipLaunchKernelGGL(linear_kernel, dim3((a->n + 63) / 64), dim3(256),
+                       lds_bytes, static_cast<hipStream_t>(stream), a->x, a->x_ld, a->w,
                        a->bias, a->m, a->n, a->k, (a->flags & CDX_LINEAR_SILU_IN) ? 1 : 0, a->out, a->out_ld);
     return check_launch();
 }
