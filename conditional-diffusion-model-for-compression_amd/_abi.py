@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcdx.so")
+# CDX_TUNE=1 selects the tuning build (make EXPERIMENTS=1: the same library + timing-ablation instantiations, used by
+# tools/conv_bench.py only); the product always loads libcdx.so.
+LIB_PATH = os.path.join(_HERE, "libcdx_tune.so" if os.environ.get("CDX_TUNE") == "1" else "libcdx.so")
 
 ABI_VERSION = 2
 CONV_UPSAMPLE2X, CONV_GN, CONV_SILU = 1, 2, 4

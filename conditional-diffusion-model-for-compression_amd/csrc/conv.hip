@@ -159,6 +159,7 @@ int validate(const cdx_conv_args* a) {
     CDX_REQUIRE((a->c1 == 0) == (a->src1 == nullptr));
     if (a->c1) CDX_REQUIRE((a->c0 % CDX_CONV_KC) == 0 && (a->c1 % CDX_CONV_KC) == 0);
     CDX_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->cout > 0);
+    CDX_REQUIRE((a->flags & ~(CDX_CONV_UPSAMPLE2X | CDX_CONV_GN | CDX_CONV_SILU)) == 0);   // unknown flag bits are an error
     CDX_REQUIRE(a->ksize == 1 || a->ksize == 3);
     CDX_REQUIRE(a->stride == 1 || (a->stride == 2 && a->ksize == 3));
     const int ups = (a->flags & CDX_CONV_UPSAMPLE2X) ? 1 : 0;
@@ -205,7 +206,12 @@ extern "C" int cdx_conv_f32(const cdx_conv_args* a, void* ws, size_t ws_bytes, c
 extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, size_t, cdx_stream_t stream) {
     int rc = validate(a);
     if (rc) return rc;
-    const bool experimental = tile >= 16;   // conv_exp.hip (16..30) / conv_wino.hip (31..): tuning variants
+#ifdef CDX_TUNING
+    const bool experimental = tile >= 16;   // conv_exp.hip (16..30) / conv_wino.hip (31..): timing ablations (libcdx_tune.so)
+#else
+    if (tile >= 16) return CDX_ENOTSUP;     // the shipped library carries no tuning / ablation instantiations
+    const bool experimental = false;
+#endif
     Tile t = tile < 0 ? select_tile(a) : experimental ? Tile{tile, 128, 128, 1} : tile_of(tile);
     if (t.wcfg < 0 || (!experimental && !tile_allowed(a, t.wcfg))) return CDX_ENOTSUP;
     if (experimental && !(a->ksize == 3 && a->stride == 1)) return CDX_ENOTSUP;
@@ -239,7 +245,9 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
         return conv_dispatch_wino(experimental ? tile : 0, p, st);
     }
     if (t.wcfg == WCFG_SMALL || t.wcfg == WCFG_SMALL_VALU) return conv_dispatch_small(p, st, t.wcfg == WCFG_SMALL_VALU);
+#ifdef CDX_TUNING
     if (experimental) return conv_dispatch_exp(logtw, t.wcfg, p, st);
+#endif
     if (a->ksize == 1) return conv_dispatch_k1s1(logtw, t.wcfg, p, st);
     if (a->stride == 1) return conv_dispatch_k3s1(logtw, t.wcfg, p, st);
     return conv_dispatch_k3s2(logtw, t.wcfg, p, st);

@@ -15,6 +15,11 @@ int validate(const cdx_conv_f16_args* a) {
     CDX_REQUIRE((a->c1 == 0) == (a->src1 == nullptr));
     if (a->c1) CDX_REQUIRE((a->c0 % 32) == 0 && (a->c1 % 32) == 0);
     CDX_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->cout > 0);
+#ifdef CDX_TUNING
+    CDX_REQUIRE((a->flags & ~(CDX_CONV_UPSAMPLE2X | CDX_CONV_GN | CDX_CONV_SILU | 0x700)) == 0);
+#else
+    CDX_REQUIRE((a->flags & ~(CDX_CONV_UPSAMPLE2X | CDX_CONV_GN | CDX_CONV_SILU)) == 0);   // unknown flag bits are an error
+#endif
     CDX_REQUIRE(a->ksize == 1 || a->ksize == 3);
     CDX_REQUIRE(a->stride == 1 || (a->stride == 2 && a->ksize == 3));
     const int ups = (a->flags & CDX_CONV_UPSAMPLE2X) ? 1 : 0;
@@ -41,7 +46,8 @@ void tile_grid(const cdx_conv_f16_args* a, int& logtw, int& tx, int& ty) {
 
 namespace cdx {
 int conv16_dispatch(int ks, int stride, int logtw, const Conv16Params& p, hipStream_t stream) {
-    // timing ablations of the dominant shape, selected by the (otherwise unused) flag bits 8..10
+#ifdef CDX_TUNING
+    // timing ablations of the dominant shape (libcdx_tune.so only), selected by flag bits 8..10
     if (ks == 3 && stride == 1 && logtw == 5 && p.abl) {
         switch (p.abl) {
             case 1: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 1>>(p, stream);
@@ -52,6 +58,7 @@ int conv16_dispatch(int ks, int stride, int logtw, const Conv16Params& p, hipStr
             default: return CDX_ENOTSUP;
         }
     }
+#endif
 #define C16(KS, ST, LT, MT) if (ks == KS && stride == ST && logtw == LT) return conv16_launch<Conv16Cfg<KS, ST, LT, MT>>(p, stream);
     C16(3, 1, 2, 4) C16(3, 1, 3, 4) C16(3, 1, 4, 4) C16(3, 1, 5, 4)
     C16(1, 1, 2, 4) C16(1, 1, 3, 4) C16(1, 1, 4, 4) C16(1, 1, 5, 4)

@@ -3,16 +3,18 @@
 // (Lavin & Gray 2016;  Y = A^T [ (G g G^T) (.) (B^T d B) ] A,  B^T, G, A^T below).
 //
 // Mapping (why this fits CDNA4): the usual obstacles are 16 accumulator sets per output block and a 4x larger
-// transformed-input image.  Here one wave per SIMD owns the whole 512-entry register file:
-//   * a workgroup (4 waves) owns 4 x 32 output pixels = 32 Winograd tiles of one image x 128 output channels;
-//     the 4 waves split the channels (32 each), so every wave holds acc[16 xi][32 tiles x 32 ch] = 256 registers;
+// transformed-input image.  Here the 512-entry unified register file of a SIMD holds them:
+//   * a workgroup (8 waves, two per SIMD) owns 4 x 32 output pixels = 32 Winograd tiles of one image x 128 output
+//     channels; wave (wn, wh) owns 32 channels and V rows {2wh, 2wh+1}: acc[8 xi][32 tiles x 32 ch] = 128 registers;
 //   * the input halo (6 x 34 pixels x 32 channels, GroupNorm/SiLU/upsample/concat applied while staging, exactly
 //     as in conv_kernel.h) sits in LDS ONCE; each lane (tile = lane & 31, channel half = lane >> 5) reads its
-//     4x4 patch and computes B^T d B IN REGISTERS (32 adds per channel) -- no transformed image in LDS;
+//     patch rows and computes B^T d B IN REGISTERS -- no transformed image in LDS;
 //   * weights U = G g G^T are transformed and packed on the host so that a lane's 16-B fragment carries four
 //     xi of one channel: [ntile][chunk][s][e][xiq][lane][4] (fragment-ordered, L2-resident, ring-prefetched);
-//   * the output transform A^T M A is in-register too (the 16 accumulators of a lane share (tile, channel));
+//   * the output transform A^T M A is in-register too (the accumulators of a lane share (tile, channel));
 //   * LDS is double buffered: the next chunk is written while this chunk's MFMAs run, one barrier per chunk.
+// (Earlier forms -- one 512-register wave per SIMD, and a persistent variant -- are in the git history of round 1;
+// both measured slower)
 // Numerics: float32 throughout; transform constants are exact (0, +-1, +-1/2) so the only extra error over the
 // direct kernel is the reassociation of the sum (measured in tests against float64).
 #pragma once
@@ -36,695 +38,6 @@ struct WinoCfg {
     static_assert(64 % (4 * PF) == 0, "ring depth (4*PF fragments) must divide the 64 fragments per chunk");
 };
 
-template <class C>
-__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p) {
-    constexpr int KC = C::KC, PS = C::PS, RS = C::RS, NPASS = C::NPASS, GPC = C::GPC, PF = C::PF;
-    __shared__ __attribute__((aligned(16))) float lds[2 * C::BUF_FLOATS];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    int bx = blockIdx.x;
-    const int tx = bx % p.tiles_x;
-    bx /= p.tiles_x;
-    const int ty = bx % p.tiles_y;
-    const int b = bx / p.tiles_y;
-    const int oy0 = ty * C::TH, ox0 = tx * C::TW;
-    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
-    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
-
-    // ---- halo loader.  Thread -> (column slot pl, channel quad q).  Passes 0..5 = halo rows 0..5 x columns 0..31
-    // (global and LDS addresses affine in the pass: base + i*row stride), pass 6 = the two leftover columns 32, 33 of
-    // all six rows (12 slots).  Per-thread state: 2 source offsets + 2 validity bits; row validity is scalar. ----
-    static_assert(C::HH == 6 && C::HW == 34 && NPASS == 7, "loader geometry is written for the 4 x 32 tile");
-    const int q = tid & 7, pl = tid >> 3;
-    const int ixa = ix0 + pl;                                     // passes 0..5: this thread's halo column
-    const bool colok = ixa >= 0 && ixa < Wv;
-    const int colx = colok ? (ixa >> p.ups) : 0;
-    const int iy6 = iy0 + (pl >> 1), ix6 = ix0 + 32 + (pl & 1);    // pass 6
-    const bool ok6 = pl < 12 && iy6 >= 0 && iy6 < Hv && ix6 >= 0 && ix6 < Wv;
-    const int soff6 = ok6 ? ((b * p.Hin + (iy6 >> p.ups)) * p.Win + (ix6 >> p.ups)) : 0;
-    const int wbase = pl * PS + q * 4;                             // LDS float offset of passes 0..5 (+ i*RS)
-    const int wbase6 = (pl >> 1) * RS + (32 + (pl & 1)) * PS + q * 4;
-    auto row_src = [&](int i) -> int {                             // scalar: source row base of halo row i, or -1
-        const int iy = iy0 + i;
-        return (iy >= 0 && iy < Hv) ? (b * p.Hin + (iy >> p.ups)) * p.Win : -1;
-    };
-    f32x4 pre[NPASS];
-    f32x4 gsc, gsh;
-    bool cvalid;
-
-    auto issue_loads = [&](int chunk) {
-        const int s = chunk >= p.nchunk0;
-        const int cl = (s ? chunk - p.nchunk0 : chunk) * KC + q * 4;
-        const int cs = p.csrc[s];
-        cvalid = cl < cs;
-        // Loads are unconditional (padding lanes read a safe in-bounds address and are zeroed at write time).
-        const float* __restrict__ base = p.src[s] + (cvalid ? cl : 0);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int rs = row_src(i);
-            pre[i] = *reinterpret_cast<const f32x4*>(base + (size_t)((rs < 0 ? 0 : rs) + colx) * cs);
-        }
-        pre[6] = *reinterpret_cast<const f32x4*>(base + (size_t)soff6 * cs);
-        if (p.gn) {
-            const int cg = cvalid ? (s ? p.csrc[0] : 0) + cl : 0;
-            gsc = *reinterpret_cast<const f32x4*>(p.gscale + (size_t)b * p.ctot + cg);
-            gsh = *reinterpret_cast<const f32x4*>(p.gshift + (size_t)b * p.ctot + cg);
-        }
-    };
-    auto write_pass = [&](float* buf, int i) {      // transform + store halo pass i of the pending chunk
-        f32x4 v = pre[i];
-        const bool ok = cvalid && (i < 6 ? (colok && row_src(i) >= 0) : ok6);
-        if (p.gn) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], gsc[e], gsh[e]);
-        }
-        if (p.silu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = silu_f<false>(v[e]);
-        }
-        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (i < 6) *reinterpret_cast<f32x4*>(&buf[wbase + i * RS]) = v;
-        else if (pl < 12) *reinterpret_cast<f32x4*>(&buf[wbase6]) = v;
-    };
-    auto write_lds = [&](float* buf) {
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i) write_pass(buf, i);
-    };
-
-    // ---- operand addressing: lane = (Winograd tile li, channel half lh) ----
-    const int li = lane & 31, lh = lane >> 5;
-    const int wty = li >> 4, wtx = li & 15;                            // tile (row, col) inside the 2 x 16 tile grid
-    const int a_base = (2 * wty) * RS + (2 * wtx) * PS + lh * 4;        // top-left pixel of the 4x4 input patch
-    const int ntile = blockIdx.y * 4 + wn;
-    const bool nvalid = ntile * 32 < p.Cout;
-    // packed weights: [ntile][chunk][s][e][xiq][lane][4]: group g = s*4+e is 4 KiB (four 1-KiB fragments)
-    // (scalar base + 32-bit lane offset: the fragment loads need no per-load 64-bit VALU address arithmetic)
-    const float* __restrict__ wp = p.w + ((size_t)(nvalid ? ntile : 0) * p.nchunks) * 16384;
-    const unsigned lane4 = lane * 4;
-
-    // Accumulators.  bias + temb + residual are injected HERE rather than added in the epilogue: with
-    // Y = A^T M A, setting M[0][0] = R00, M[0][3] = -R01, M[3][0] = -R10, M[3][3] = R11 adds exactly R to the 2x2
-    // output.  The 64 residual loads thus overlap the first halo fetch and cost no registers of their own.
-    const int n = ntile * 32 + li;
-    const bool nok = nvalid && n < p.Cout;
-    f32x16 acc[16];
-#pragma unroll
-    for (int x = 0; x < 16; ++x)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
-    if (nok) {
-        float add = p.bias ? p.bias[n] : 0.f;
-        if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
-        // NOTE: the residual test is hoisted out of the unrolled loops on purpose -- a per-element "load or not"
-        // makes hipcc branch around every load and wait vmcnt(0) each time (64 serial HBM round trips).
-        if (p.residual && !(C::OPT & 256)) {   // OPT 256 (ablation): no residual loads
-            float rv[64];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int oy = oy0 + 2 * (tile >> 4), ox = ox0 + 2 * (tile & 15);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int y = min(oy + (k >> 1), p.Hout - 1), x = min(ox + (k & 1), p.Wout - 1);   // clamped: masked at store
-                    rv[r * 4 + k] = p.residual[(((size_t)b * p.Hout + y) * p.Wout + x) * p.Cout + n];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[0][r] = rv[r * 4 + 0] + add;
-                acc[3][r] = -(rv[r * 4 + 1] + add);
-                acc[12][r] = -(rv[r * 4 + 2] + add);
-                acc[15][r] = rv[r * 4 + 3] + add;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[0][r] = add;
-                acc[3][r] = -add;
-                acc[12][r] = -add;
-                acc[15][r] = add;
-            }
-        }
-    }
-
-    // Weight fragments: 1 KiB each (64 lanes x 16 B), consumed in order f = g*4 + xiq; a ring of RF fragments
-    // (RF*4 MFMAs = RF*256 cycles of cover) is kept in flight and wraps into the next chunk / the tail pad.
-    constexpr int RF = 4 * PF;
-    f32x4 ring[RF];
-#pragma unroll
-    for (int f = 0; f < RF; ++f) ring[f] = *reinterpret_cast<const f32x4*>(wp + f * 256 + lane4);
-
-    // ---- pipeline prologue: chunk 0 in buffer 0, chunk 1 in flight ----
-    issue_loads(0);
-    write_lds(lds);
-    if (p.nchunks > 1) issue_loads(1);
-    __syncthreads();
-
-    if (!nvalid) {
-        // A wave whose 32 output channels lie beyond cout only helps with the staging and the barriers.
-        for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-            if (chunk + 1 < p.nchunks) {
-                write_lds(lds + ((chunk + 1) & 1) * C::BUF_FLOATS);
-                if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
-            }
-            __syncthreads();
-        }
-        return;
-    }
-
-    // One chunk = 16 groups g = (s, e) of 16 MFMAs.  Software pipeline inside the chunk:
-    //   * the lane's 4x4 input patch is read in HALVES of two channels (16 x ds_read_b64 = channels e0, e0+1 of one
-    //     8-channel group): half h+1 is issued at the start of half h, a full 32 MFMAs (2048 cycles) before use;
-    //   * the transformed values of group g+1 are computed into the OTHER register set while group g's MFMAs
-    //     run -- distinct registers, so no VALU write waits for an in-flight MFMA to read its operand.
-    using f32x2 = __attribute__((ext_vector_type(2))) float;
-    auto load_half = [&](const float* buf, int hh, f32x2 (&dst)[16]) {
-        int ab = a_base;
-        asm volatile("" : "+v"(ab));              // opaque: no CSE of LDS reads across halves
-        __builtin_assume((ab & 1) == 0);
-        const int coff = (hh >> 1) * 8 + (hh & 1) * 2;       // channel offset inside the chunk (+ 4*lh in a_base)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb)
-                dst[a * 4 + bb] = *reinterpret_cast<const f32x2*>(&buf[ab + a * RS + bb * PS + coff]);
-    };
-    auto transform = [&](const f32x2 (&d)[16], int c, float (&v)[16]) {   // B^T d B for channel c of the half
-        float r[4][4];
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-            const float t0 = d[0 + bb][c], t1 = d[4 + bb][c], t2 = d[8 + bb][c], t3 = d[12 + bb][c];
-            r[0][bb] = t0 - t2;
-            r[1][bb] = t1 + t2;
-            r[2][bb] = t2 - t1;
-            r[3][bb] = t1 - t3;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[i * 4 + 0] = r[i][0] - r[i][2];
-            v[i * 4 + 1] = r[i][1] + r[i][2];
-            v[i * 4 + 2] = r[i][2] - r[i][1];
-            v[i * 4 + 3] = r[i][1] - r[i][3];
-        }
-    };
-
-    auto chunk_body = [&](const int chunk, const bool more) __attribute__((always_inline)) {
-        const float* cur = lds + (chunk & 1) * C::BUF_FLOATS;
-        float* nxt = lds + ((chunk + 1) & 1) * C::BUF_FLOATS;
-        const float* __restrict__ wc = wp + (size_t)chunk * 16384;
-        f32x2 dh[2][16];
-        float vv[2][16];
-        load_half(cur, 0, dh[0]);
-        transform(dh[0], 0, vv[0]);
-#pragma unroll
-        for (int g = 0; g < GPC; ++g) {
-            const int hh = g >> 1;
-            if ((g & 1) == 0 && hh + 1 < 8) load_half(cur, hh + 1, dh[(hh + 1) & 1]);      // prefetch the next half
-            if (g + 1 < GPC) {   // next group's operands (OPT 8, ablation: raw patch values, no transform adds)
-                if constexpr (C::OPT & 8) {
-#pragma unroll
-                    for (int x = 0; x < 16; ++x) vv[(g + 1) & 1][x] = dh[((g + 1) >> 1) & 1][x][(g + 1) & 1];
-                } else transform(dh[((g + 1) >> 1) & 1], (g + 1) & 1, vv[(g + 1) & 1]);
-            }
-            // Second half of the chunk: stage the NEXT chunk into the other buffer, one halo pass per MFMA group
-            // (its ~30 VALU + one ds_write_b128 hide under the group's 16 MFMAs), then start the loads of the
-            // chunk after that.
-            if (more && !(C::OPT & 4)) {   // OPT 4 (ablation): no staging of later chunks
-                constexpr int G0 = GPC - NPASS - 1;          // first staging group
-                if (g >= G0 && g < G0 + NPASS) write_pass(nxt, g - G0);
-                if (g == G0 + NPASS && chunk + 2 < p.nchunks) issue_loads(chunk + 2);
-            }
-#pragma unroll
-            for (int xq = 0; xq < 4; ++xq) {      // xi = 4*xq + j: row xq of V, column j
-                const int f = g * 4 + xq;
-                const f32x4 bq = ring[f % RF];
-                if constexpr (!(C::OPT & 1))   // OPT 1 (ablation): never refill the weight ring
-                    ring[f % RF] = *reinterpret_cast<const f32x4*>(wc + (f + RF) * 256 + lane4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[xq * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[g & 1][xq * 4 + j], bq[j], acc[xq * 4 + j], 0, 0, 0);
-            }
-            if constexpr (C::OPT & 64) {
-                // pin an even interleave inside the group: MFMA, 3 VALU, (1 LDS read), every 4th: 1 global load
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    if ((i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    if ((i & 7) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);   // keep each group's loads / VALU / MFMAs where they are written
-        }
-    };
-
-    for (int chunk = 0; chunk + 1 < p.nchunks; ++chunk) {
-        chunk_body(chunk, true);
-        __syncthreads();
-    }
-    chunk_body(p.nchunks - 1, false);
-
-    // ---- output transform A^T M A (in registers) + epilogue ----
-    if constexpr (C::OPT & 16) {   // OPT 16 (timing ablation): no output transform / residual / stores
-        float keep = 0.f;
-#pragma unroll
-        for (int x = 0; x < 16; ++x)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) keep += acc[x][r];
-        if (keep == 123.456f) p.out[0] = keep;
-        return;
-    }
-    // Opaque copies of the tile origin / lane half: otherwise hipcc hoists all 64 output-address computations
-    // above the main loop and spills them (and accumulators) to scratch.
-    int eoy0 = oy0, eox0 = ox0, elh = lh;
-    asm volatile("" : "+s"(eoy0), "+s"(eox0), "+v"(elh));
-    // Packed stores: for each of the 4 output positions (a, bb) of a tile, blocks of 4 tile-registers are transposed
-    // across lane quads (quad_transpose), so a lane stores 4 consecutive channels of ONE pixel as 16 bytes -- 16 stores
-    // per lane instead of 64.  GroupNorm sums are reduced in that layout.
-    const int q4 = li & 3;
-    const int cq = ntile * 32 + (li & ~3);
-    const bool quad_ok = cq < p.Cout;
-    const bool vec_ok = (p.out_ld & 3) == 0 && cq + 4 <= p.out_ld;      // else: scalar stores (e.g. out_ld == cout == 3)
-    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float y[4][4];      // [register 4k+i][output position a*2+bb] for this lane's channel
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 4 * k + i;
-            float t[2][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                t[0][j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
-                t[1][j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                y[i][a * 2 + 0] = t[a][0] + t[a][1] + t[a][2];
-                y[i][a * 2 + 1] = t[a][1] - t[a][2] - t[a][3];
-            }
-        }
-        const int tile = 8 * k + q4 + 4 * elh;                       // the tile this lane owns after the transposes
-        const int oy = eoy0 + 2 * (tile >> 4), ox = eox0 + 2 * (tile & 15);
-#pragma unroll
-        for (int pos = 0; pos < 4; ++pos) {
-            float x[4] = {y[0][pos], y[1][pos], y[2][pos], y[3][pos]};
-            quad_transpose(x, q4);                                    // x[c] = channel cq + c at pixel (oy + pos/2, ox + pos%2)
-            const int py = oy + (pos >> 1), px = ox + (pos & 1);
-            if (quad_ok && py < p.Hout && px < p.Wout) {
-                const size_t pix = ((size_t)b * p.Hout + py) * p.Wout + px;
-                if (vec_ok) *reinterpret_cast<f32x4*>(p.out + pix * p.out_ld + cq) = f32x4{x[0], x[1], x[2], x[3]};
-                else
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (cq + c < p.Cout) p.out[pix * p.out_ld + cq + c] = x[c];
-                if (p.stats) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const double dv = (double)x[c];
-                        s1[c] += dv;
-                        s2[c] = fma(dv, dv, s2[c]);
-                    }
-                }
-            }
-        }
-    }
-    if (p.stats) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            s1[c] += __shfl_xor(s1[c], 1);
-            s2[c] += __shfl_xor(s2[c], 1);
-            s1[c] += __shfl_xor(s1[c], 2);
-            s2[c] += __shfl_xor(s2[c], 2);
-            s1[c] += __shfl_xor(s1[c], 32);
-            s2[c] += __shfl_xor(s2[c], 32);
-        }
-        if (lh == 0 && q4 == 0 && quad_ok) {
-            const int slot = ty * p.tiles_x + tx;
-            const int nslots = p.tiles_y * p.tiles_x;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (cq + c < p.Cout) {
-                    double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + cq + c) * 2;
-                    o[0] = s1[c];
-                    o[1] = s2[c];
-                }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Persistent form: one workgroup per CU walks tiles item = blockIdx.x, += gridDim.x.  The chunk pipeline runs
-// straight through tile boundaries (the next tile's first halo chunk is staged under this tile's last chunk), and
-// the next tile's residual tile (128 px x 128 ch = 64 KiB) is brought into LDS by LDS-DMA (global_load_lds, no
-// VGPRs) under the last chunk too, so a tile boundary costs only the output transform + stores.
-// LDS: 2 x 30 KiB halo buffers + 64 KiB residual tile = 124 KiB (one workgroup per CU by register count anyway).
-template <class C>
-__global__ __launch_bounds__(256, 1) void conv_wino_persist_kernel(const ConvParams p) {
-    constexpr int KC = C::KC, PS = C::PS, RS = C::RS, NPASS = C::NPASS, GPC = C::GPC, PF = C::PF;
-    __shared__ __attribute__((aligned(16))) float lds[2 * C::BUF_FLOATS + 128 * 128];
-    float* const lds_res = lds + 2 * C::BUF_FLOATS;
-
-    // Raw barrier: with an LDS-DMA possibly in flight hipcc turns __syncthreads() into vmcnt(0) + s_barrier, which
-    // would drain the weight ring and the halo loads at every chunk.  LDS writes are ordered by the explicit
-    // lgkmcnt(0); the DMA is ordered by later in-order vmcnt waits of its issuing wave plus these barriers.
-    auto wg_barrier = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // one statement: nothing can be scheduled in between
-    };
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_per_image = p.tiles_x * p.tiles_y;
-    const int total = tiles_per_image * p.B;
-    const int stride = gridDim.x;
-    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
-
-    // ---- halo loader.  Thread -> (column slot pl, channel quad q).  Passes 0..5 = halo rows 0..5 x columns 0..31
-    // (global and LDS addresses affine in the pass: base + i*row stride), pass 6 = the two leftover columns 32, 33 of
-    // all six rows (12 slots).  Per-thread state: 2 source offsets + 2 validity bits; row validity is scalar. ----
-    // (geometry follows the tile whose chunks are being ISSUED)
-    static_assert(C::HH == 6 && C::HW == 34 && NPASS == 7, "loader geometry is written for the 4 x 32 tile");
-    const int q = tid & 7, pl = tid >> 3;
-    const int wbase = pl * PS + q * 4;
-    const int wbase6 = (pl >> 1) * RS + (32 + (pl & 1)) * PS + q * 4;
-    int lb = 0, liy0 = 0;            // image / first halo row of the loader's tile (scalar)
-    int colx = 0, soff6 = 0;         // per-thread source offsets
-    bool colok = false, ok6 = false;
-    auto set_loader_tile = [&](int item) {
-        int t = item;
-        const int tx = t % p.tiles_x;
-        t /= p.tiles_x;
-        const int ty = t % p.tiles_y;
-        lb = t / p.tiles_y;
-        liy0 = ty * C::TH - 1;
-        const int ix0 = tx * C::TW - 1;
-        const int ixa = ix0 + pl;
-        colok = ixa >= 0 && ixa < Wv;
-        colx = colok ? (ixa >> p.ups) : 0;
-        const int iy6 = liy0 + (pl >> 1), ix6 = ix0 + 32 + (pl & 1);
-        ok6 = pl < 12 && iy6 >= 0 && iy6 < Hv && ix6 >= 0 && ix6 < Wv;
-        soff6 = ok6 ? ((lb * p.Hin + (iy6 >> p.ups)) * p.Win + (ix6 >> p.ups)) : 0;
-    };
-    auto row_src = [&](int i) -> int {
-        const int iy = liy0 + i;
-        return (iy >= 0 && iy < Hv) ? (lb * p.Hin + (iy >> p.ups)) * p.Win : -1;
-    };
-    f32x4 pre[NPASS];
-    f32x4 gsc, gsh;
-    bool cvalid;
-    unsigned rowmask = 0;            // row validity of the chunk held in `pre` (its tile may differ from the loader's)
-    auto issue_loads = [&](int chunk) {
-        const int s = chunk >= p.nchunk0;
-        const int cl = (s ? chunk - p.nchunk0 : chunk) * KC + q * 4;
-        const int cs = p.csrc[s];
-        cvalid = cl < cs;
-        const float* __restrict__ base = p.src[s] + (cvalid ? cl : 0);
-        rowmask = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int rs = row_src(i);
-            rowmask |= rs >= 0 ? (1u << i) : 0u;
-            pre[i] = *reinterpret_cast<const f32x4*>(base + (size_t)((rs < 0 ? 0 : rs) + colx) * cs);
-        }
-        pre[6] = *reinterpret_cast<const f32x4*>(base + (size_t)soff6 * cs);
-        if (p.gn) {
-            const int cg = cvalid ? (s ? p.csrc[0] : 0) + cl : 0;
-            gsc = *reinterpret_cast<const f32x4*>(p.gscale + (size_t)lb * p.ctot + cg);
-            gsh = *reinterpret_cast<const f32x4*>(p.gshift + (size_t)lb * p.ctot + cg);
-        }
-    };
-    auto write_pass = [&](float* buf, int i) {
-        f32x4 v = pre[i];
-        const bool ok = cvalid && (i < 6 ? (colok && ((rowmask >> i) & 1u)) : ok6);
-        if (p.gn) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], gsc[e], gsh[e]);
-        }
-        if (p.silu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = silu_f<false>(v[e]);
-        }
-        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (i < 6) *reinterpret_cast<f32x4*>(&buf[wbase + i * RS]) = v;
-        else if (pl < 12) *reinterpret_cast<f32x4*>(&buf[wbase6]) = v;
-    };
-    // the issue cursor walks (item, chunk) in execution order, one chunk ahead of the staging, two of the MFMAs
-    int is_item = blockIdx.x, is_chunk = 0;
-    auto issue_next = [&]() {          // precondition: is_item < total
-        if (is_chunk == 0) set_loader_tile(is_item);
-        issue_loads(is_chunk);
-        if (++is_chunk == p.nchunks) {
-            is_chunk = 0;
-            is_item += stride;
-        }
-    };
-
-    // ---- residual tile of an item -> LDS, by LDS-DMA: wave wn copies tile row wn (32 px x 512 B) ----
-    auto dma_residual = [&](int item) {
-        int t = item;
-        const int tx = t % p.tiles_x;
-        t /= p.tiles_x;
-        const int ty = t % p.tiles_y;
-        const int b = t / p.tiles_y;
-        const int oy = min(ty * C::TH + wn, p.Hout - 1);
-        int ch = blockIdx.y * 128 + (lane & 31) * 4;
-        if (ch + 4 > p.Cout) ch = 0;                                   // lanes past cout: any valid address (masked later)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ox = min(tx * C::TW + 2 * i + (lane >> 5), p.Wout - 1);
-            const float* g = p.residual + (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + ch;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(lds_res + (wn * 32 + 2 * i) * 128),
-                                             16, 0, 0);
-        }
-    };
-
-    // ---- operand addressing ----
-    const int li = lane & 31, lh = lane >> 5;
-    const int wty = li >> 4, wtx = li & 15;
-    const int a_base = (2 * wty) * RS + (2 * wtx) * PS + lh * 4;
-    const int ntile = blockIdx.y * 4 + wn;
-    const bool nvalid = ntile * 32 < p.Cout;
-    const int n = ntile * 32 + li;
-    const bool nok = nvalid && n < p.Cout;
-    const float* __restrict__ wp = p.w + ((size_t)(nvalid ? ntile : 0) * p.nchunks) * 16384;
-    const unsigned lane4 = lane * 4;
-    const float bias_n = (nok && p.bias) ? p.bias[n] : 0.f;
-    const float rscale = p.residual ? 1.f : 0.f;      // no residual: the LDS tile is zero-filled once and ignored
-
-    f32x16 acc[16];
-    constexpr int RF = 4 * PF;
-    f32x4 ring[RF];
-
-    using f32x2 = __attribute__((ext_vector_type(2))) float;
-    auto load_half = [&](const float* buf, int hh, f32x2 (&dst)[16]) {
-        int ab = a_base;
-        asm volatile("" : "+v"(ab));
-        __builtin_assume((ab & 1) == 0);
-        const int coff = (hh >> 1) * 8 + (hh & 1) * 2;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb)
-                dst[a * 4 + bb] = *reinterpret_cast<const f32x2*>(&buf[ab + a * RS + bb * PS + coff]);
-    };
-    auto transform = [&](const f32x2 (&d)[16], int c, float (&v)[16]) {
-        float r[4][4];
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-            const float t0 = d[0 + bb][c], t1 = d[4 + bb][c], t2 = d[8 + bb][c], t3 = d[12 + bb][c];
-            r[0][bb] = t0 - t2;
-            r[1][bb] = t1 + t2;
-            r[2][bb] = t2 - t1;
-            r[3][bb] = t1 - t3;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[i * 4 + 0] = r[i][0] - r[i][2];
-            v[i * 4 + 1] = r[i][1] + r[i][2];
-            v[i * 4 + 2] = r[i][2] - r[i][1];
-            v[i * 4 + 3] = r[i][1] - r[i][3];
-        }
-    };
-
-    int vpar = 0;   // LDS buffer parity of the chunk being computed
-    // one chunk of MFMAs; `stage` = there is a following chunk in this workgroup's stream (write it into the other
-    // buffer during the second half), `issue` = and one after that (start its global loads)
-    auto chunk_body = [&](const int chunk, const bool stage, const bool issue) __attribute__((always_inline)) {
-        const float* cur = lds + vpar * C::BUF_FLOATS;
-        float* nxt = lds + (vpar ^ 1) * C::BUF_FLOATS;
-        const float* __restrict__ wc = wp + (size_t)chunk * 16384;
-        const float* __restrict__ wnext = chunk + 1 < p.nchunks ? wc + 16384 : wp;   // next tile: same weights again
-        f32x2 dh[2][16];
-        float vv[2][16];
-        load_half(cur, 0, dh[0]);
-        transform(dh[0], 0, vv[0]);
-#pragma unroll
-        for (int g = 0; g < GPC; ++g) {
-            const int hh = g >> 1;
-            if ((g & 1) == 0 && hh + 1 < 8) load_half(cur, hh + 1, dh[(hh + 1) & 1]);
-            if (g + 1 < GPC) transform(dh[((g + 1) >> 1) & 1], (g + 1) & 1, vv[(g + 1) & 1]);
-            if (stage) {
-                constexpr int G0 = GPC - NPASS - 1;
-                if (g >= G0 && g < G0 + NPASS) write_pass(nxt, g - G0);
-                if (g == G0 + NPASS && issue) issue_next();
-            }
-#pragma unroll
-            for (int xq = 0; xq < 4; ++xq) {
-                const int f = g * 4 + xq;
-                const f32x4 bq = ring[f % RF];
-                // the ring wraps into the next chunk; past the tile's last chunk it re-reads chunk 0 (same weights for
-                // the next tile), so fragments are always in flight
-                ring[f % RF] = *reinterpret_cast<const f32x4*>((f + RF < 64 ? wc + (f + RF) * 256 : wnext + (f + RF - 64) * 256) + lane4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[xq * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[g & 1][xq * 4 + j], bq[j], acc[xq * 4 + j], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    if constexpr (C::OPT & 128) {
-        // OPT 128 (experiment): de-phase the 256 persistent workgroups -- without it every CU stores its tile and
-        // fetches the next residual tile in the same microsecond.  8 phases spread over ~one chunk time.
-        const int ph = (blockIdx.x * 5) & 7;
-        for (int i = 0; i < ph * 3; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-    // ---- stream prologue: first tile's chunk 0 staged, chunk 1 (or the next tile's chunk 0) in flight ----
-    int item = blockIdx.x;           // grid.x <= total
-    issue_next();
-#pragma unroll
-    for (int i = 0; i < NPASS; ++i) write_pass(lds, i);
-    const int my_chunks = ((total - 1 - (int)blockIdx.x) / stride + 1) * p.nchunks;   // chunks in this workgroup's stream
-    int done = 0;                    // chunks computed so far
-    if (my_chunks > 1) issue_next();
-    if (p.residual) dma_residual(item);
-    else
-        for (int i = tid * 4; i < 128 * 128; i += 1024) *reinterpret_cast<f32x4*>(lds_res + i) = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int f = 0; f < RF; ++f) ring[f] = *reinterpret_cast<const f32x4*>(wp + f * 256 + lane4);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    if (!nvalid) {
-        // a wave whose 32 channels lie beyond cout only helps with staging, DMA and barriers
-        for (; item < total; item += stride) {
-            const bool next_item = item + stride < total;
-            for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-                if (chunk == 1 && next_item && p.residual) dma_residual(item + stride);
-                if (done + 1 < my_chunks) {
-#pragma unroll
-                    for (int i = 0; i < NPASS; ++i) write_pass(lds + (vpar ^ 1) * C::BUF_FLOATS, i);
-                    if (done + 2 < my_chunks) issue_next();
-                }
-                ++done;
-                vpar ^= 1;
-                wg_barrier();
-            }
-        }
-        return;
-    }
-
-    for (; item < total; item += stride) {
-        int t = item;
-        const int tx = t % p.tiles_x;
-        t /= p.tiles_x;
-        const int ty = t % p.tiles_y;
-        const int b = t / p.tiles_y;
-        const int oy0 = ty * C::TH, ox0 = tx * C::TW;
-
-        // accumulator init: bias + temb + residual injected through M (see conv_wino_kernel)
-        {
-            float add = bias_n;
-            if (nok && p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
-#pragma unroll
-            for (int x = 0; x < 16; ++x)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int py = 2 * (tile >> 4), px = 2 * (tile & 15);
-                float v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    v[k] = add + rscale * lds_res[((py + (k >> 1)) * 32 + px + (k & 1)) * 128 + wn * 32 + li];
-                acc[0][r] = v[0];
-                acc[3][r] = -v[1];
-                acc[12][r] = -v[2];
-                acc[15][r] = v[3];
-            }
-        }
-        const bool next_item = item + stride < total;
-        for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-            // Residual of the NEXT tile: LDS-DMA issued at the start of this tile's second chunk -- one barrier after
-            // every wave has consumed the current copy (accumulator init above), and a whole tile of younger,
-            // waited-for loads ahead of its first use (vmcnt retires in order), so no drain is needed.
-            if (chunk == 1 && next_item && p.residual) dma_residual(item + stride);
-            const bool stage = done + 1 < my_chunks, issue = done + 2 < my_chunks;
-            chunk_body(chunk, stage, issue);
-            ++done;
-            vpar ^= 1;
-            wg_barrier();
-        }
-
-        // ---- output transform + stores for this tile ----
-        {
-            double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int oy = oy0 + 2 * (tile >> 4), ox = ox0 + 2 * (tile & 15);
-                float tt[2][4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    tt[0][j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
-                    tt[1][j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
-                }
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const float y[2] = {tt[a][0] + tt[a][1] + tt[a][2], tt[a][1] - tt[a][2] - tt[a][3]};
-#pragma unroll
-                    for (int bb = 0; bb < 2; ++bb) {
-                        if (nok && oy + a < p.Hout && ox + bb < p.Wout) {
-                            const size_t pix = ((size_t)b * p.Hout + oy + a) * p.Wout + ox + bb;
-                            const float v = y[bb];
-                            p.out[pix * p.out_ld + n] = v;
-                            if (p.stats) {
-                                const double dv = (double)v;
-                                s1 += dv;
-                                s2 = fma(dv, dv, s2);
-                            }
-                        }
-                    }
-                }
-            }
-            if (p.stats) {
-                s1 += __shfl_xor(s1, 32);
-                s2 += __shfl_xor(s2, 32);
-                if (lh == 0 && nok) {
-                    const int slot = ty * p.tiles_x + tx;
-                    double* o = p.stats + (((size_t)b * tiles_per_image + slot) * p.Cout + n) * 2;
-                    o[0] = s1;
-                    o[1] = s2;
-                }
-            }
-        }
-    }
-}
-
-template <class C>
-inline int conv_wino_persist_launch(const ConvParams& p, hipStream_t stream) {
-    const int total = p.tiles_x * p.tiles_y * p.B;
-    dim3 grid(total < 256 ? total : 256, ceil_div(p.Cout, C::BN));   // one workgroup per CU (256 CUs)
-    hipLaunchKernelGGL(conv_wino_persist_kernel<C>, grid, dim3(256), 0, stream, p);
-    return check_launch();
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // 8-wave form: two waves per SIMD.  Wave (wn = N quarter, wh = half) owns V rows {2*wh, 2*wh + 1} of every tile, i.e. 8
 // of the 16 transform-domain products: 128 accumulator registers, half of the input-transform adds, 12 of the 16 patch
@@ -732,7 +45,9 @@ inline int conv_wino_persist_launch(const ConvParams& p, hipStream_t stream) {
 // VALU / LDS / staging work issues under the other's MFMAs (the overlap a lone 512-register wave cannot have).
 // A^T M A is linear in M: each half produces a partial 2x2 output per tile and the halves are summed once per tile
 // through LDS (registers 0..7 of a lane are finished by half 0, 8..15 by half 1).
-// bias + temb + residual enter through the accumulator init as in conv_wino_kernel (row 0 -> half 0, row 3 -> half 1).
+// bias + temb + residual enter through the accumulator init: with Y = A^T M A, setting M[0][0] = R00, M[0][3] = -R01,
+// M[3][0] = -R10, M[3][3] = R11 adds exactly R to the 2x2 output (row 0 -> half 0, row 3 -> half 1), so the residual loads
+// overlap the first halo fetch and cost no registers of their own.
 // (The body is a device function templated on the half WH: everything that depends on which V rows a wave owns is
 // resolved at compile time.  With a runtime `wh` hipcc if-converts the branches -- BOTH halves' transforms plus a
 // v_cndmask per value -- and a two-armed lambda inside one function re-creates the accumulator-phi spills.)
@@ -1150,13 +465,6 @@ template <class C>
 inline int conv_wino8_launch(const ConvParams& p, hipStream_t stream) {
     dim3 grid(p.tiles_x * p.tiles_y * p.B, ceil_div(p.Cout, C::BN));
     hipLaunchKernelGGL(conv_wino8_kernel<C>, grid, dim3(512), 0, stream, p);
-    return check_launch();
-}
-
-template <class C>
-inline int conv_wino_launch(const ConvParams& p, hipStream_t stream) {
-    dim3 grid(p.tiles_x * p.tiles_y * p.B, ceil_div(p.Cout, C::BN));
-    hipLaunchKernelGGL(conv_wino_kernel<C>, grid, dim3(256), 0, stream, p);
     return check_launch();
 }
 

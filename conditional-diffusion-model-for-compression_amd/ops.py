@@ -12,8 +12,16 @@ import torch
 from . import _abi
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(t=None) -> int:
+    """The current HIP stream of tensor t's device (default: of the current device)."""
+    return torch.cuda.current_stream(None if t is None else t.device).cuda_stream
+
+
+def _call(op: str, args, ws_ptr, ws_bytes, t) -> None:
+    """One C-ABI launch on the current stream of t's device, with that device current (hipLaunchKernelGGL launches on
+    the CURRENT device: a tensor on cuda:1 while cuda:0 is current would otherwise be touched by a device-0 kernel)."""
+    with torch.cuda.device(t.device):
+        _abi.call(op, args, ws_ptr, ws_bytes, _stream(t))
 
 
 def _ptr(t, byte_off: int = 0):
@@ -105,7 +113,7 @@ def conv16(pc: PackedConv16, src0, src1=None, *, out_dtype=torch.float16, want_s
     out = torch.zeros(B, hout, wout, kw.get("out_ld") or pc.cout, device=src0.device, dtype=out_dtype)
     a = conv16_args(pc, src0, src1, out, **kw)
     stats = conv16_stats_buffer(a, src0.device) if want_stats else None
-    _abi.call("conv_f16", a, None, 0, _stream())
+    _call("conv_f16", a, None, 0, src0)
     return (out, stats) if want_stats else out
 
 
@@ -167,8 +175,8 @@ def gn_finalize(stats0, stats1, hw, gamma, beta, groups, eps=1e-5, want_moments=
     scale, shift = torch.empty(B, C, device=dev), torch.empty(B, C, device=dev)
     mean = torch.empty(B, groups, device=dev) if want_moments else None
     rstd = torch.empty(B, groups, device=dev) if want_moments else None
-    _abi.call("gn_finalize_f32", gn_finalize_args(stats0, stats1, hw, gamma, beta, groups, scale, shift, eps, mean, rstd),
-              None, 0, _stream())
+    _call("gn_finalize_f32", gn_finalize_args(stats0, stats1, hw, gamma, beta, groups, scale, shift, eps, mean, rstd),
+          None, 0, stats0)
     return (scale, shift, mean, rstd) if want_moments else (scale, shift)
 
 
@@ -188,7 +196,8 @@ def conv(pc: PackedConv, src0, src1=None, **kw):
     a = conv_args(pc, src0, src1, out, **kw)
     stats = conv_stats_buffer(a, src0.device) if want_stats else None
     import ctypes
-    _abi.check(_abi.lib().cdx_conv_f32_tile(ctypes.byref(a), tile, None, 0, _stream()), "cdx_conv_f32_tile")
+    with torch.cuda.device(src0.device):
+        _abi.check(_abi.lib().cdx_conv_f32_tile(ctypes.byref(a), tile, None, 0, _stream(src0)), "cdx_conv_f32_tile")
     return (out, stats) if want_stats else out
 
 
@@ -215,7 +224,7 @@ def gn_stats(src0, src1, gamma, beta, groups, eps=1e-5, want_moments=False):
     rstd = torch.empty(B, groups, device=dev) if want_moments else None
     a = gn_stats_args(src0, src1, gamma, beta, groups, scale, shift, eps, mean, rstd)
     wp, wb, keep = _ws(_abi.workspace_bytes("gn_stats_f32", a), dev)
-    _abi.call("gn_stats_f32", a, wp, wb, _stream())
+    _call("gn_stats_f32", a, wp, wb, src0)
     return (scale, shift, mean, rstd) if want_moments else (scale, shift)
 
 
@@ -239,7 +248,7 @@ def attention(q, k, v, heads: int, head_dim: int = 64):
     out = torch.empty(B, nq, c, device=q.device, dtype=q.dtype)
     a = attn_args(q, k, v, out, batch=B, nq=nq, nk=nk, heads=heads, head_dim=head_dim,
                   q_ld=c, k_ld=k.shape[-1], v_ld=v.shape[-1], out_ld=c)
-    _abi.call("attn_f16" if q.dtype == torch.float16 else "attn_f32", a, None, 0, _stream())
+    _call("attn_f16" if q.dtype == torch.float16 else "attn_f32", a, None, 0, q)
     return out
 
 
@@ -255,14 +264,14 @@ def linear_args(x, w, bias, out, *, silu_in=False, m=None, out_off=0, out_ld=Non
 
 def linear(x, w, bias=None, silu_in=False):
     out = torch.empty(x.shape[0], w.shape[0], device=x.device)
-    _abi.call("linear_f32", linear_args(x, w, bias, out, silu_in=silu_in), None, 0, _stream())
+    _call("linear_f32", linear_args(x, w, bias, out, silu_in=silu_in), None, 0, x)
     return out
 
 
 def timestep_embedding(t, dim: int):
     out = torch.empty(t.shape[0], dim, device=t.device)
     a = _abi.TimestepEmbeddingArgs(_ptr(t), t.shape[0], dim, _ptr(out))
-    _abi.call("timestep_embedding_f32", a, None, 0, _stream())
+    _call("timestep_embedding_f32", a, None, 0, t)
     return out
 
 
@@ -270,7 +279,7 @@ def gauss_fill(x, channels: int, seed: int, first_image: int, noise_stream: int)
     """x [B, HW.., ld] NHWC buffer: channels [0, channels) <- N(0,1) of stream (seed, image, noise_stream)."""
     B, ld = x.shape[0], x.shape[-1]
     a = _abi.GaussFillArgs(_ptr(x), ld, B, x.numel() // (B * ld), channels, seed, first_image, noise_stream)
-    _abi.call("gauss_fill_f32", a, None, 0, _stream())
+    _call("gauss_fill_f32", a, None, 0, x)
     return x
 
 
@@ -279,7 +288,7 @@ def diffusion_update(x, eps, channels, coef, *, clip_x0=True, seed=0, first_imag
     a = _abi.DiffusionUpdateArgs(_ptr(x), ld, _ptr(eps), eps.shape[-1], B, x.numel() // (B * ld), channels,
                                  coef.ca, coef.cb, coef.cx, coef.c0, coef.ce, coef.sigma, int(clip_x0),
                                  seed, first_image, noise_stream)
-    _abi.call("diffusion_update_f32", a, None, 0, _stream())
+    _call("diffusion_update_f32", a, None, 0, x)
     return x
 
 
@@ -287,7 +296,7 @@ def cond_embed(cond_nchw, x, c_off: int):
     B, cc, hc, wc = cond_nchw.shape
     _, h, w, ld = x.shape
     a = _abi.CondEmbedArgs(_ptr(cond_nchw), cc, hc, wc, _ptr(x), ld, c_off, B, h, w)
-    _abi.call("cond_embed_f32", a, None, 0, _stream())
+    _call("cond_embed_f32", a, None, 0, x)
     return x
 
 
@@ -295,5 +304,5 @@ def export_image(x, channels: int, lo=-1.0, hi=1.0):
     B, h, w, ld = x.shape
     out = torch.empty(B, channels, h, w, device=x.device)
     a = _abi.ExportImageArgs(_ptr(x), ld, B, h * w, channels, lo, hi, _ptr(out))
-    _abi.call("export_image_f32", a, None, 0, _stream())
+    _call("export_image_f32", a, None, 0, x)
     return out

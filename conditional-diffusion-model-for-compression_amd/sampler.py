@@ -27,6 +27,7 @@ class Sampler:
             raise ValueError("only eta = 0 (deterministic DDIM) is defined")
         self.unet, self.method, self.clip_x0 = unet, method, clip_x0
         self.use_graph = use_graph       # replay the UNet forward as one hipGraph launch (host-bound workloads)
+        self._graphs = {}                # batch -> hipGraph of the forward; owned by THIS sampler (the plan stays eager)
         self.schedule = make_schedule(schedule)
 
     @torch.no_grad()
@@ -38,12 +39,20 @@ class Sampler:
         `x_T` [B,C,H,W], if given, replaces the generator's x_T (tiled decode: crops of one noise field).
         """
         net, cfg = self.unet, self.unet.cfg
+        with torch.cuda.device(net.device):      # every launch below targets the net's device, whatever the caller's is
+            return self._sample(cond, steps, seed, first_image, trace, x_T)
+
+    def _sample(self, cond, steps, seed, first_image, trace, x_T):
+        net, cfg = self.unet, self.unet.cfg
         B, C = cond.shape[0], cfg["in_channels"]
         p = net.plan(B)
+        graph = None
         if self.use_graph:
-            p.capture()
+            if B not in self._graphs:
+                self._graphs[B] = p.capture()
+            graph = self._graphs[B]
         coefs = step_coefficients(self.schedule, steps, self.method)
-        st = torch.cuda.current_stream().cuda_stream
+        st = torch.cuda.current_stream(net.device).cuda_stream
         load_cond(p, cfg, cond)
         if x_T is None:
             ops.gauss_fill(p.xin, C, seed, first_image, STREAM_XT)
@@ -58,14 +67,16 @@ class Sampler:
             if c.t != t_host:
                 p.t.fill_(c.t)
                 t_host = c.t
-            p.run(st)
+            if graph is not None:
+                graph.replay()               # on the current stream (= st)
+            else:
+                p.run(st)
             upd.ca, upd.cb, upd.cx, upd.c0, upd.ce, upd.sigma = c.ca, c.cb, c.cx, c.c0, c.ce, c.sigma
             upd.noise_stream = STREAM_STEP0 + k
             _abi.call("diffusion_update_f32", upd, None, 0, st)
             if trace is not None:
                 trace.append(p.xin[..., :C].permute(0, 3, 1, 2).clone())
         return ops.export_image(p.xin, C, -1.0, 1.0)
-
 
     def sample_tiled(self, cond: torch.Tensor, steps: int, **kw) -> torch.Tensor:
         """Decode an image larger than the UNet's native size tile by tile (tiling.py, S5)."""

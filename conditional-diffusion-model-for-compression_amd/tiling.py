@@ -39,6 +39,11 @@ def tile_plan(h: int, w: int, tile: int, overlap: int) -> tuple[list[int], list[
 def sample_tiled(sampler, cond: torch.Tensor, steps: int, *, overlap: int = 64, seed: int = 0, first_image: int = 0,
                  tiles_per_call: int = 16) -> torch.Tensor:
     """cond [B, Cc, hc, wc] -> x_0 [B, C, 16*hc, 16*wc] decoded through the sampler's (tile-sized) UNet."""
+    with torch.cuda.device(sampler.unet.device):
+        return _sample_tiled(sampler, cond, steps, overlap, seed, first_image, tiles_per_call)
+
+
+def _sample_tiled(sampler, cond, steps, overlap, seed, first_image, tiles_per_call):
     net, cfg = sampler.unet, sampler.unet.cfg
     if sampler.method != "ddim" or cfg["cond_mode"] != "concat":
         raise ValueError("tiled decode is defined for the deterministic DDIM sampler with concat conditioning")
@@ -68,5 +73,5 @@ def sample_tiled(sampler, cond: torch.Tensor, steps: int, *, overlap: int = 64, 
     y0 = torch.tensor(ys, dtype=torch.int32, device=dev)
     x0 = torch.tensor(xs, dtype=torch.int32, device=dev)
     a = _abi.TileBlendArgs(tiles.data_ptr(), B, C, T, len(ys), len(xs), y0.data_ptr(), x0.data_ptr(), H, W, out.data_ptr())
-    _abi.call("tile_blend_f32", a, None, 0, torch.cuda.current_stream().cuda_stream)
+    _abi.call("tile_blend_f32", a, None, 0, torch.cuda.current_stream(dev).cuda_stream)
     return out

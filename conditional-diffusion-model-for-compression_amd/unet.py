@@ -33,7 +33,6 @@ class _Plan:
         cfg, g, dev = net.cfg, net.graph, net.device
         B, H, ch = batch, cfg["image_size"], cfg["base_channels"]
         self.calls = []          # (bound C function, args struct, ws_ptr, ws_bytes)
-        self.graph = None        # optional hipGraph of the launch list (capture())
         self._keep = []
         self._ws_need = 0
         self._ws_calls = []      # indices of calls that use the shared workspace
@@ -180,31 +179,32 @@ class _Plan:
         self.calls.append((getattr(_abi.lib(), f"cdx_{op}"), args, None, nbytes))
 
     def capture(self):
-        """Record the launch list into a hipGraph (torch.cuda.CUDAGraph on a side stream); afterwards run() replays the
-        graph with ONE launch instead of ~140-230.  Every buffer address and argument is static (the timestep is read
-        from self.t on the device), so one capture serves the whole sampling loop.  Worth it only when a forward is
-        host-bound (small images / batch 1); at cfg2 the host already runs ahead of ~47 ms of GPU work per step."""
-        if self.graph is not None:
-            return
-        self.run()                       # warm-up outside capture (lazy module loads)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.run()
-        self.graph = g
+        """Record the launch list into a NEW hipGraph (torch.cuda.CUDAGraph on a side stream) and return it; the caller
+        (a Sampler with use_graph=True) owns it and replays it with ONE launch instead of ~140-230.  Every buffer
+        address and argument is static (the timestep is read from self.t on the device), so one capture serves the
+        whole sampling loop.  The plan itself keeps no graph: run() is always the eager launch list.  Worth it only
+        when a forward is host-bound (small images / batch 1); at cfg2 the host already runs ahead of the GPU."""
+        with torch.cuda.device(self.net.device):
+            self.run()                       # warm-up outside capture (lazy module loads)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.run()
+        return g
 
     def run(self, stream: int | None = None):
-        """Enqueue one UNet forward: reads self.xin / self.t (/ self.ctx), writes self.eps."""
-        if self.graph is not None and not torch.cuda.is_current_stream_capturing():
-            self.graph.replay()
-            return
+        """Enqueue one UNet forward (eagerly) on `stream` (default: the current stream of the net's device): reads
+        self.xin / self.t (/ self.ctx), writes self.eps.  hipLaunchKernelGGL launches on the CURRENT device, so the
+        net's device is made current for the duration."""
         import ctypes
-        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
-        byref = ctypes.byref
-        for fn, a, wp, wb in self.calls:
-            rc = fn(byref(a), wp, wb, st)
-            if rc:
-                _abi.check(rc, fn.__name__)
+        dev = self.net.device
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+            byref = ctypes.byref
+            for fn, a, wp, wb in self.calls:
+                rc = fn(byref(a), wp, wb, st)
+                if rc:
+                    _abi.check(rc, fn.__name__)
 
 
 class UNet:
@@ -220,6 +220,10 @@ class UNet:
         self.cfg = validate_unet_config(cfg)
         self.graph = build_graph(self.cfg)
         self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(f"UNet (HIP backend) needs a cuda device, got {device!r}; there is no CPU fallback in the product path")
+        if self.device.index is None:        # pin the ordinal now: every later launch targets THIS device
+            self.device = torch.device("cuda", torch.cuda.current_device())
         if params is None:
             params = init_params(self.cfg, seed)
         g = self.graph
@@ -268,7 +272,8 @@ class UNet:
 
     def plan(self, batch: int) -> _Plan:
         if batch not in self._plans:
-            self._plans[batch] = _Plan(self, batch)
+            with torch.cuda.device(self.device):
+                self._plans[batch] = _Plan(self, batch)
         return self._plans[batch]
 
     @torch.no_grad()
@@ -279,11 +284,12 @@ class UNet:
         p = self.plan(B)
         dev = self.device
         C = cfg["in_channels"]
-        p.xin[..., :C] = x.to(dev, torch.float32).permute(0, 2, 3, 1)
-        p.t.copy_(t.to(dev, torch.int32))
-        load_cond(p, cfg, cond)
-        p.run()
-        return p.eps[..., :cfg["out_channels"]].permute(0, 3, 1, 2).contiguous()
+        with torch.cuda.device(dev):
+            p.xin[..., :C] = x.to(dev, torch.float32).permute(0, 2, 3, 1)
+            p.t.copy_(t.to(dev, torch.int32))
+            load_cond(p, cfg, cond)
+            p.run()
+            return p.eps[..., :cfg["out_channels"]].permute(0, 3, 1, 2).contiguous()
 
     __call__ = forward
 

@@ -230,7 +230,7 @@ typedef struct cdx_linear_args {
     const float* x; int32_t x_ld; /* [m, x_ld] */
     const float* w;               /* [n, k] row-major (torch layout) */
     const float* bias;            /* [n] or NULL */
-    int32_t m, n, k;              /* k multiple of 4, m <= 64 */
+    int32_t m, n, k;              /* k multiple of 4, k <= 1024 (else CDX_ENOTSUP); any m */
     int32_t flags;
     float* out; int32_t out_ld;
 } cdx_linear_args;

@@ -111,3 +111,48 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle", text, flags=re.M), f
+
+
+def test_unknown_flag_bits_are_rejected(lib):
+    """The shipped library carries no timing-ablation variants: unknown flag bits and tuning tile ids are errors."""
+    a = cdx._abi.ConvArgs()
+    a.src0 = a.wpacked = a.out = 4096
+    a.c0, a.batch, a.hin, a.win, a.hout, a.wout, a.cout, a.ksize, a.stride, a.out_ld = 32, 1, 32, 32, 32, 32, 32, 3, 1, 32
+    assert lib.cdx_conv_select_tile(ctypes.byref(a)) >= 0
+    a.flags = 0x100
+    assert lib.cdx_conv_select_tile(ctypes.byref(a)) == -1
+    a.flags = 0
+    before = lib.cdx_launch_count()
+    for tile in (16, 31, 35, 44, 54):
+        assert lib.cdx_conv_f32_tile(ctypes.byref(a), tile, None, 0, None) == -4      # CDX_ENOTSUP, nothing launched
+    assert lib.cdx_launch_count() == before
+    h = cdx._abi.ConvF16Args()
+    h.src0 = h.wpacked = h.out = 4096
+    h.c0, h.batch, h.hin, h.win, h.hout, h.wout, h.cout, h.ksize, h.stride, h.out_ld = 32, 1, 32, 32, 32, 32, 32, 3, 1, 32
+    h.flags = 0x300
+    assert lib.cdx_conv_f16(ctypes.byref(h), None, 0, None) == -1
+    l = cdx._abi.LinearArgs()
+    l.x = l.w = l.out = 4096
+    l.m, l.n, l.k, l.x_ld, l.out_ld, l.flags = 100, 8, 8, 8, 8, 2
+    assert lib.cdx_linear_f32(ctypes.byref(l), None, 0, None) == -1
+
+
+def test_store_hazard_isa_check():
+    """Every wide buffer store with a register soffset in the generated gfx950 code keeps its wait states
+    (tools/isa_check.py; the Winograd epilogue is the user of common.h buf_store4), and the checker itself
+    recognises an unprotected store."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_check", os.path.join(ROOT, "tools", "isa_check.py"))
+    ic = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ic)
+    n, bad = ic.check("\tbuffer_store_dwordx4 v[2:5], v6, s[8:11], s3 offen\n\tv_mov_b32_e32 v5, v9\n")
+    assert n == 1 and len(bad) == 1
+    n, bad = ic.check("\tbuffer_store_dwordx4 v[2:5], v6, s[8:11], s3 offen\n\t;;#ASMSTART\n\ts_nop 1\n\tv_mov_b32_e32 v5, v9\n")
+    assert n == 1 and not bad
+    users = [f for f in sorted(os.listdir(ic.CSRC)) if f.endswith(".hip") and
+             ("buf_store4" in open(os.path.join(ic.CSRC, f)).read() or
+              any("buf_store4" in open(os.path.join(ic.CSRC, h)).read() for h in re.findall(r'#include "(\w+\.h)"', open(os.path.join(ic.CSRC, f)).read()) if h != "common.h"))]
+    assert "conv_wino.hip" in users
+    for f in users:
+        n, bad = ic.check(ic.device_asm(os.path.join(ic.CSRC, f)))
+        assert not bad and (n > 0 or f != "conv_wino.hip"), (f, n, bad)

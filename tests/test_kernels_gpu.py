@@ -70,7 +70,7 @@ def tiles_for(k, s, wout=0, cout=999, cin=999):
         return (-1, 0, 1, 2) + ((5, 6) if wout < 32 else ())
     if s == 2:
         return (-1, 3, 4, 5)
-    return (-1, 0, 1, 2, 5, 6) + ((8, 9) if wout >= 32 and cout <= 4 else ()) + ((10,) if wout >= 32 and cin <= 8 and cout > 4 else ()) + ((7, 31, 35) if wout >= 32 else ())     # 7 = Winograd (8-wave form); experimental ids: 31 = 4-wave form, 35 = persistent 4-wave form
+    return (-1, 0, 1, 2, 5, 6) + ((8, 9) if wout >= 32 and cout <= 4 else ()) + ((10,) if wout >= 32 and cin <= 8 and cout > 4 else ()) + ((7,) if wout >= 32 else ())     # 7 = Winograd F(2x2,3x3)
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
@@ -86,7 +86,7 @@ def test_conv_plain(cdx_mod, case):
     for tile in tiles_for(k, s, want.shape[-1], co, ci):
         got = nchw(cdx_mod.ops.conv(pc, xd, stride=s, upsample=up, tile=tile))
         assert got.shape == want.shape
-        close(got, want, 4e-6 if tile in (7, 31, 35) else 2e-6, f"conv tile {tile}")
+        close(got, want, 4e-6 if tile == 7 else 2e-6, f"conv tile {tile}")
 
 
 @pytest.mark.parametrize("B,c0,c1,co,H,W,groups", [
@@ -121,7 +121,7 @@ def test_conv_fused_gn_silu_concat_temb_residual(cdx_mod, B, c0, c1, co, H, W, g
     pc = ops.PackedConv(w.numpy(), bias.numpy(), c0, c1)
     for tile in tiles_for(3, 1, W, co):
         got = nchw(ops.conv(pc, s0, s1, gn=(sc, sh), silu=True, temb=temb.cuda(), temb_off=2, residual=nhwc(res), tile=tile))
-        close(got, want, 5e-6 if tile in (7, 31, 35) else 3e-6, f"fused conv tile {tile}")
+        close(got, want, 5e-6 if tile == 7 else 3e-6, f"fused conv tile {tile}")
 
 
 @pytest.mark.parametrize("B,ci,c_a,c_b,H,W,k,s,tile", [(2, 32, 64, 32, 32, 32, 3, 1, -1), (1, 64, 128, 0, 16, 16, 3, 1, -1), (2, 32, 96, 64, 8, 8, 1, 1, -1),
@@ -156,7 +156,7 @@ def test_conv_epilogue_stats_match_standalone_gn(cdx_mod, B, ci, c_a, c_b, H, W,
 def test_winograd_repeatable_across_launch_sequences(cdx_mod):
     """Flake detector (a parked variant of the 8-wave kernel returned 16 wrong values in 2-15 % of launches, only when
     other kernels / fresh tensors ran in between): many launches of the shipped Winograd kernel, different shapes
-    interleaved, outputs pre-filled with NaN, each compared with the independent 4-wave kernel."""
+    interleaved, outputs pre-filled with NaN, each compared with the independent direct (non-Winograd) kernel."""
     ops = cdx_mod.ops
     cases = [(2, 32, 128, 32, 32, False), (2, 64, 128, 16, 16, True), (1, 96, 128, 64, 64, False), (2, 32, 160, 40, 72, False)]
     for rnd_i in range(25):
@@ -166,7 +166,7 @@ def test_winograd_repeatable_across_launch_sequences(cdx_mod):
             pc = ops.PackedConv(w.numpy(), rnd(co, seed=3).numpy(), ci)
             ho, wo = (H * 2, W * 2) if up else (H, W)
             kw = dict(residual=nhwc(rnd(B, co, ho, wo, seed=3000 + rnd_i)), temb=rnd(B, co, seed=4000 + rnd_i).cuda()) if rnd_i & 1 else {}
-            ref = ops.conv(pc, x, upsample=up, tile=31, **kw)      # odd rounds: + temb + residual (the LDS-DMA path)
+            ref = ops.conv(pc, x, upsample=up, tile=0, **kw)      # odd rounds: + temb + residual
             got = torch.full_like(ref, float("nan"))
             ops.conv(pc, x, upsample=up, tile=7, out=got, **kw)
             assert not torch.isnan(got).any(), f"round {rnd_i} case {j}: unwritten outputs"
@@ -241,13 +241,17 @@ def test_attention_peaked_rows(cdx_mod):
 
 
 # ------------------------------------------------------------------ linear / temb
-@pytest.mark.parametrize("M,N,K,silu", [(16, 512, 128, False), (16, 512, 512, True), (1, 1000, 256, True), (3, 37, 64, False), (64, 64, 256, True)])
+@pytest.mark.parametrize("M,N,K,silu", [(16, 512, 128, False), (16, 512, 512, True), (1, 1000, 256, True), (3, 37, 64, False), (64, 64, 256, True),
+                                         (33, 200, 512, True), (64, 8704, 512, True), (128, 96, 768, True), (100, 130, 1024, False)])   # M > 32: row blocks (grid.y)
 def test_linear(cdx_mod, M, N, K, silu):
     x, w, b = rnd(M, K, seed=30), rnd(N, K, seed=31, scale=1 / math.sqrt(K)), rnd(N, seed=32)
     xin = F.silu(x.double()) if silu else x.double()
     want = F.linear(xin, w.double(), b.double())
     got = cdx_mod.ops.linear(x.cuda(), w.cuda(), b.cuda(), silu_in=silu).cpu()
     close(got, want, 2e-6, "linear")
+    if M > 16:      # a row's bits do not depend on M or on the row block it falls in (sharding invariance)
+        one = cdx_mod.ops.linear(x[M - 1:].cuda(), w.cuda(), b.cuda(), silu_in=silu).cpu()
+        assert torch.equal(one[0], got[M - 1])
 
 
 def test_timestep_embedding(cdx_mod):

@@ -5,6 +5,9 @@ kernel tuning (interleaved rounds in one process, cdna guide rule 24) and the ta
   python tools/conv_bench.py [--shape B,H,W,C0,C1,COUT,K,S] [--tiles -1,0,6] [--gn] [--rounds 5] [--iters 10]
 """
 import argparse, ctypes, os, sys, math
+if any(int(t) >= 16 for a in sys.argv[1:] if a.startswith("--tiles") for t in a.split("=")[-1].split(",") if t.lstrip("-").isdigit()) or \
+        any(sys.argv[i] == "--tiles" and any(int(t) >= 16 for t in sys.argv[i + 1].split(",")) for i in range(1, len(sys.argv) - 1)):
+    os.environ["CDX_TUNE"] = "1"      # ablation tiles live in libcdx_tune.so (make -C .../csrc EXPERIMENTS=1)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import cdx

@@ -17,7 +17,7 @@ for rnd in range(rounds):
         pc = ops.PackedConv(w, np.random.default_rng(3).standard_normal(co).astype(np.float32), ci)
         ho, wo = (H * 2, W * 2) if up else (H, W)
         kw = dict(residual=torch.randn(B, ho, wo, co, generator=g).cuda(), temb=torch.randn(B, co, generator=g).cuda()) if (rnd & 1) else {}
-        ref = ops.conv(pc, x, upsample=bool(up), tile=31, **kw)      # odd rounds: + temb + residual (the LDS-DMA path)
+        ref = ops.conv(pc, x, upsample=bool(up), tile=0, **kw)      # independent direct kernel; odd rounds: + temb + residual
         junk = torch.randn(1 << 20, device='cuda')      # perturb the allocator / caches
         b = torch.full_like(ref, float('nan'))
         ops.conv(pc, x, upsample=bool(up), tile=TILE, out=b, **kw)
