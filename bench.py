@@ -13,10 +13,17 @@ identical cost, and K defaults to 100 (one complete decode).  Inputs (cond, x_T)
 before the timed region.  One process per GPU; images are independent, so there is no data-path
 collective (torch.distributed is used only for the barrier and the max-over-ranks of the elapsed time).
 
+The timed steps are Sampler.step() calls -- the same function Sampler.sample() loops over (no private copy of the
+loop here); the shard arithmetic (which images this rank decodes) and the barrier / max-over-ranks timing come from
+cdx.shard (ShardJob, timed_region), the driver the CPU gloo test exercises.  `sample_call` additionally times ONE
+complete Sampler.sample() of this rank's shard (x_T draw, all steps, export) after the step loop.
+
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel symbol (the implicit-GEMM conv instantiation carrying most FLOPs):
-                  algorithmic FLOPs of its launches in one forward / their summed durations, measured with
-                  HIP events on the launch stream, against the fp32 MFMA peak (157.3 TFLOP/s).
+  roofline     -- the dominant kernel symbol (the conv instantiation carrying most FLOPs): MFMA FLOPs it EXECUTES in
+                  one forward / the summed durations of its launches, measured with HIP events on the launch stream,
+                  against the MFMA peak of the instruction it runs on (fp32: 157.3 TFLOP/s).  `frac` <= 1 by
+                  construction; for the Winograd kernel the direct-convolution (algorithmic) FLOP rate is reported
+                  beside it as algorithmic_tflops / algorithmic_over_direct_peak.
   cpu_baseline -- the stock-torch CPU oracle (oracle/, kind "port": the reference ships no sampler) timed
                   on this host's cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -79,12 +86,38 @@ def fn_is_half(a) -> bool:
     return type(a).__name__ == "ConvF16Args"
 
 
+def csrc_sha16() -> str:
+    """Hash of the kernel sources this process runs (csrc/*.hip, *.h, include/cdx.h): stamps PMC digests in profiles/ so
+    that a traffic figure measured on another build is not passed off as this build's."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "conditional-diffusion-model-for-compression_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))) + [os.path.join(ROOT, "include", "cdx.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def kernel_model(variant) -> dict:
+    """What the kernel behind a conv variant executes on the matrix pipe, per ALGORITHMIC (direct-convolution) FLOP."""
+    tile = variant[3]
+    if tile.startswith("wino"):
+        # Winograd F(2x2,3x3): 16 transform-domain multiply-adds per 2x2 output tile where the direct algorithm needs 36
+        return {"name": "conv_wino8_kernel<WinoCfg<2,0>> (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
+                "executed_per_algorithmic": 1.0 / 2.25, "peak": FP32_MFMA_PEAK_TFLOPS, "wino": True, "flops_per_mfma_cycle": 64.0}
+    if tile.startswith("f16"):
+        return {"name": "conv16_kernel<Conv16Cfg> (v_mfma_f32_32x32x16_f16)", "executed_per_algorithmic": 1.0,
+                "peak": FP16_MFMA_PEAK_TFLOPS, "wino": False, "flops_per_mfma_cycle": 1024.0}
+    return {"name": "conv_kernel<ConvCfg> (direct implicit GEMM on v_mfma_f32_32x32x2_f32)", "executed_per_algorithmic": 1.0,
+            "peak": FP32_MFMA_PEAK_TFLOPS, "wino": False, "flops_per_mfma_cycle": 64.0}
+
+
 def measure_dominant_kernel(plan, torch, reps=3):
     """Per-launch HIP-event timing of every conv launch of one forward; returns the roofline object for the
     kernel symbol with the most FLOPs, plus a per-variant table."""
     import ctypes
     st = torch.cuda.current_stream()
-    convs = [(i, c) for i, c in enumerate(plan.calls) if c[0].__name__ == "cdx_conv_f32"]
     table, shapes = {}, {}
     for rep in range(reps + 1):
         evs = []
@@ -112,35 +145,46 @@ def measure_dominant_kernel(plan, torch, reps=3):
             u["flops"] += conv_flops(a); u["ms"] += ms; u["n"] += 1
     dom = max(table, key=lambda k: table[k]["flops"])
     d = table[dom]
-    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-    wino = dom[3].startswith("wino")
-    half = dom[3].startswith("f16")
-    peak = FP16_MFMA_PEAK_TFLOPS if half else FP32_MFMA_PEAK_TFLOPS
-    # Winograd F(2x2,3x3) issues 16 multiply-adds where the direct algorithm (which `achieved` counts) needs 36.
-    executed = achieved / 2.25 if wino else achieved
-    roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": None,
-            "kernel": ("conv_wino8_kernel<WinoCfg<2,0>> (Winograd F(2x2,3x3), ksize %d stride %d log2TW %d tile %s)" if wino else
-                       "conv16_kernel<Conv16Cfg> (fp16 MFMA, ksize %d stride %d log2TW %d tile %s)" if half else
-                       "conv_kernel<ConvCfg<ksize %d, stride %d, log2TW %d, tile %s>>") % dom,
-            "flop_accounting": "achieved = ALGORITHMIC direct-convolution FLOPs (2*Cin*Cout*9*H*W*B) / measured time"
-                               + ("; this kernel is Winograd F(2x2,3x3): it issues 2.25x fewer MFMA FLOPs than that, so "
-                                  "frac can exceed 1; executed_* is the MFMA work actually issued" if wino else ""),
-            "executed_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4),
+    km = kernel_model(dom)
+    algorithmic = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    executed = algorithmic * km["executed_per_algorithmic"]
+    peak = km["peak"]
+    roof = {"bound": "mfma", "achieved": round(executed, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(executed / peak, 4), "traffic": None,
+            "kernel": km["name"] + " [ksize %d stride %d log2TW %d tile %s]" % dom,
+            "flop_accounting": "achieved = MFMA FLOPs the kernel EXECUTES / measured time (frac <= 1 against the peak of the "
+                               "instruction it runs on)"
+                               + ("; Winograd F(2x2,3x3) executes 1/2.25 of the direct-convolution FLOPs (2*Cin*Cout*9*H*W*B), "
+                                  "whose rate is algorithmic_tflops" if km["wino"] else ""),
+            "algorithmic_tflops": round(algorithmic, 2), "algorithmic_over_direct_peak": round(algorithmic / peak, 4),
             "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_forward": d["launches"] // reps,
             "flop_share_of_forward": round(d["flops"] / sum(v["flops"] for v in table.values()), 4),
             "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+            # MFMA instructions x issue cycles, summed over all waves of an average launch (unpadded shapes): the value
+            # SQ_VALU_MFMA_BUSY_CYCLES should report per launch (tools/pmc_digest.py mfma ... unit check)
+            "mfma_cycles_per_launch_expected": round(d["flops"] * km["executed_per_algorithmic"] / d["launches"] / km["flops_per_mfma_cycle"]),
             "hbm_GBps_at_algorithmic_bytes": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)}
-    # HBM bytes per launch of this kernel: PMC counters cannot be read from inside the process, so the figure
-    # comes from the committed rocprofv3 --pmc passes over this same command (profiles/r01_traffic.json).
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if wino and "wino" in tr["kernel"]:
+    # HBM bytes per launch of this kernel: PMC counters cannot be read from inside the process, so the figure comes from
+    # the committed rocprofv3 --pmc passes over this same command -- accepted only if they were taken on THIS build of
+    # the kernels (csrc hash) and for THIS kernel; otherwise traffic stays null and the stale digest is named.
+    sha = csrc_sha16()
+    roof["csrc_sha16"] = sha
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if not (name.endswith("_traffic.json")):
+            continue
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        same_kernel = tr.get("kernel", "").split("<")[0] == km["name"].split("<")[0]
+        if same_kernel and tr.get("csrc_sha16") == sha:
             roof["traffic"] = round(tr["hbm_bytes_per_launch"])
             roof["traffic_over_algorithmic"] = round(tr["hbm_bytes_per_launch"] / roof["algorithmic_bytes_per_launch"], 3)
-            roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2 x FETCH + WRITE)"
-    except (OSError, KeyError, ValueError):
-        pass
+            roof["traffic_source"] = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build: 2 x FETCH + WRITE)"
+            break
+        if same_kernel and "traffic_from_other_build" not in roof:
+            roof["traffic_from_other_build"] = {"file": f"profiles/{name}", "csrc_sha16": tr.get("csrc_sha16"),
+                                                "hbm_bytes_per_launch": round(tr["hbm_bytes_per_launch"])}
     per_variant = {"k%ds%d_tw%d_%s" % k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                          "ms_per_forward": round(v["ms"] / reps, 3)}
                    for k, v in sorted(table.items(), key=lambda kv: -kv[1]["flops"])}
@@ -164,14 +208,14 @@ def host_cores() -> int:
     return int(env) if env else min(n, 16)
 
 
-def cpu_baseline(cfg, params, cond_cpu, torch, budget_s=25.0):
-    """Stock-torch CPU oracle: seconds per UNet forward + update at batch 1, bounded sample."""
+def cpu_baseline(cfg, run, params, cond_cpu, torch, budget_s=25.0):
+    """Stock-torch CPU oracle: seconds per UNet forward + update at batch 1 (one image / one tile), bounded sample."""
     import oracle
     ncores = host_cores()
     torch.set_num_threads(ncores)
-    H = cfg["image_size"]
+    H, S = cfg["image_size"], run["steps"]
     x = oracle.sampler_ref.noise_ref(0, 0, 1, 1, (3, H, H))
-    coefs = oracle.step_coefficients_ref(100, "ddim")
+    coefs = oracle.step_coefficients_ref(S, run["method"])
     c1 = cond_cpu[:1]
     times = []
     t_begin = time.perf_counter()
@@ -179,14 +223,21 @@ def cpu_baseline(cfg, params, cond_cpu, torch, budget_s=25.0):
         t0 = time.perf_counter()
         eps = oracle.unet_forward_ref(cfg, params, x, torch.full((1,), t, dtype=torch.int64), c1)
         x = cx * x + c0 * (ca * x + cb * eps).clamp(-1, 1) + ce * eps
+        if sigma != 0.0:
+            x = x + sigma * oracle.sampler_ref.noise_ref(0, 0, 1, 16 + k, (3, H, H))
         times.append(time.perf_counter() - t0)
         if k >= 1 and time.perf_counter() - t_begin > budget_s:
             break
     timed = times[1:] if len(times) > 1 else times    # first step = warm-up
     sec_per_step = sum(timed) / len(timed)
-    return {"value": round(1.0 / (sec_per_step * 100), 6), "unit": "images/s", "cores": ncores, "kind": "port",
-            "sample": f"1 image x {len(timed)} of 100 DDIM steps at 256x256 (1 warm-up step dropped; every step "
-                      f"costs the same), scaled to 100 steps; {sec_per_step:.2f} s/step, torch {torch.__version__} CPU"}
+    tiles = 1
+    if "image" in run:
+        import cdx
+        tiles = len(cdx.tile_origins(run["image"], H, run["overlap"])) ** 2
+    return {"value": round(1.0 / (sec_per_step * S * tiles), 6), "unit": "images/s", "cores": ncores, "kind": "port",
+            "sample": f"1 image x {len(timed)} of {S} {run['method'].upper()} steps at {H}x{H} (1 warm-up step dropped; every step "
+                      f"costs the same), scaled to {S} steps" + (f" x {tiles} tiles per {run['image']}^2 image" if tiles > 1 else "")
+                      + f"; {sec_per_step:.2f} s/step, float32, torch {torch.__version__} CPU"}
 
 
 def main():
@@ -194,10 +245,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU (BASELINE.json configs[1]: 16)")
+    ap.add_argument("--batch", type=int, default=None, help="images (cfg5: tiles) per GPU and sampler call; default: the config's per-GPU batch")
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-sample-call", action="store_true", help="skip the extra timing of one complete Sampler.sample()")
     ap.add_argument("--details", action="store_true", help="print the per-variant conv table to stderr")
     args = ap.parse_args()
 
@@ -218,59 +270,33 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+    # This rank's shard of the job: weak scaling, B units per GPU (cdx.shard owns the rank arithmetic).
     cfg, run = cdx.named_config(args.config)
-    B = args.batch
-    # cfg5: the unit of work of a step is a batch of 256^2 TILES (fp16); an image is (image/stride)^2 tiles
-    tiles_per_image = 1
-    if "image" in run:
-        tiles_per_image = len(cdx.tile_origins(run["image"], cfg["image_size"], run["overlap"])) ** 2
-    params = cdx.init_params(cfg, seed=0)
-    net = cdx.UNet(cfg, params, device=f"cuda:{local}")
-    sampler = cdx.Sampler(net, method=run["method"])
-    first_image = rank * B                                  # weak scaling: B images per GPU
-    sb = cdx.synthetic_batch(cfg, 0, first_image, B)
-    cond = torch.from_numpy(sb["cond"]).cuda()
-    plan = net.plan(B)
+    B = args.batch or {"cfg5": 16}.get(args.config, cdx.shard.IMAGES_PER_CALL[args.config])
+    tiled = "image" in run
+    tiles_per_image = len(cdx.tile_origins(run["image"], cfg["image_size"], run["overlap"])) ** 2 if tiled else 1
+    images_per_gpu = 1 if tiled else B            # cfg5: the step loop runs B TILES; sample_call decodes one whole image
+    job = cdx.shard.ShardJob(images_per_gpu * world, args.config, rank=rank, world=world, device=f"cuda:{local}",
+                             images_per_call=images_per_gpu)
+    sampler, net = job.sampler, job.sampler.unet
+    sync = torch.cuda.synchronize
 
-    # inputs resident before the timed region
-    from cdx.unet import load_cond
-    load_cond(plan, cfg, cond)
-    cdx.ops.gauss_fill(plan.xin, cfg["in_channels"], 0, first_image, cdx.rng.STREAM_XT)
-    coefs = cdx.step_coefficients(sampler.schedule, run["steps"], run["method"])
-    st = torch.cuda.current_stream().cuda_stream
-    upd = cdx._abi.DiffusionUpdateArgs()
-    upd.x, upd.x_ld, upd.eps, upd.eps_ld = plan.xin.data_ptr(), plan.xin.shape[-1], plan.eps.data_ptr(), plan.eps.shape[-1]
-    upd.batch, upd.hw, upd.channels = B, cfg["image_size"] ** 2, cfg["in_channels"]
-    upd.clip_x0, upd.seed, upd.first_image = 1, 0, first_image
+    # inputs resident in HBM before the timed region: Sampler.begin() loads cond and draws x_T
+    if tiled:
+        conds, xts, _, _ = cdx.tiling.tile_batch(net, job.cond(job.lo, 1), run["overlap"], job.seed, job.lo)
+        reps_ = -(-B // conds.shape[0])
+        state = sampler.begin(conds.repeat(reps_, 1, 1, 1)[:B].contiguous(), run["steps"], seed=job.seed,
+                              x_T=xts.repeat(reps_, 1, 1, 1)[:B].contiguous())
+    else:
+        state = sampler.begin(job.cond(job.lo, B), run["steps"], seed=job.seed, first_image=job.lo)
+    plan = state.plan
 
-    def step(k):
-        c = coefs[k % len(coefs)]
-        plan.t.fill_(c.t)
-        plan.run(st)
-        upd.ca, upd.cb, upd.cx, upd.c0, upd.ce, upd.sigma = c.ca, c.cb, c.cx, c.c0, c.ce, c.sigma
-        upd.noise_stream = cdx.rng.STREAM_STEP0 + k
-        cdx._abi.call("diffusion_update_f32", upd, None, 0, st)
+    def steps(k0, n):
+        for k in range(k0, k0 + n):
+            sampler.step(state, k % run["steps"])      # the function Sampler.sample() loops over
 
-    for k in range(args.warmup):
-        step(k)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
+    steps(0, args.warmup)
+    elapsed = cdx.timed_region(lambda: steps(args.warmup, args.steps), dist, sync)
     assert torch.isfinite(plan.xin).all(), "non-finite state after the timed region"
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -279,7 +305,7 @@ def main():
     total_flops = sum(fl.values())
     line = {
         "metric": ("decoded images/sec (whole node), 256x256 100-step DDIM" if args.config in ("cfg2", "cfg3") else
-                   f"decoded images/sec (whole node), {args.config}: {cfg['image_size']}x{cfg['image_size']} {run['steps']}-step {run['method'].upper()}"),
+                   f"decoded images/sec (whole node), {args.config}: {run.get('image', cfg['image_size'])}^2 {run['steps']}-step {run['method'].upper()}"),
         "value": round(images_per_s, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16" if cfg["dtype"] == "fp16" else "f32", "data": "synthetic",
@@ -289,19 +315,34 @@ def main():
                                (f"BASELINE.json {args.config}: {cfg['image_size']}^2 x3, {cfg['base_channels']}-ch UNet, dtype "
                                 f"{cfg['dtype']}, cond_mode {cfg['cond_mode']}, {run['steps']}-step {run['method'].upper()}, "
                                 f"batch {B} per GPU" + (f" = tiles of a {run['image']}^2 image ({tiles_per_image} tiles/image, "
-                                                       f"overlap {run['overlap']})" if tiles_per_image > 1 else "")),
-                   "images_per_gpu": B, "global_batch": B * world, "image": f"{cfg['image_size']}x{cfg['image_size']}x3",
-                   "sampler_steps_per_image": run["steps"], "parallelism": f"replica x{world} (no collective)"},
+                                                       f"overlap {run['overlap']})" if tiled else "")),
+                   "images_per_gpu": B / tiles_per_image, "global_batch": B * world, "image": f"{cfg['image_size']}x{cfg['image_size']}x3",
+                   "sampler_steps_per_image": run["steps"], "parallelism": f"replica x{world} (no collective)",
+                   "timed": "Sampler.step() x steps (cdx.sampler), shard + timing from cdx.shard.ShardJob / timed_region"},
         "algorithmic_gflop_per_step": round(total_flops / 1e9, 1),
-        "achieved_tflops_whole_step": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
+        "algorithmic_tflops_whole_step": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
     }
+    if not args.no_sample_call:
+        # ONE complete decode of this rank's shard through the API entry point itself: Sampler.sample (cfg5:
+        # Sampler.sample_tiled of one whole image) -- x_T draw, every step, export; max over ranks.
+        out = {}
+        sec = cdx.timed_region(lambda: out.update(job.decode()), dist, sync)
+        n_img = images_per_gpu * world
+        line["sample_call"] = {"entry": "Sampler.sample_tiled(cond, steps)" if tiled else "Sampler.sample(cond, steps)",
+                               "images": n_img, "steps": run["steps"], "seconds": round(sec, 4),
+                               "images_per_s": round(n_img / sec, 4),
+                               "ms_per_step_equiv": round(sec * 1e3 / (run["steps"] * (-(-tiles_per_image // B) if tiled else 1)), 3)}
+        assert all(torch.isfinite(v).all() for v in out.values())
     if rank == 0 and not args.no_roofline:
         roof, table = measure_dominant_kernel(plan, torch)
         line["roofline"] = roof
         if args.details:
             print(json.dumps({"conv_variants": table, "flops": fl}, indent=1), file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(dict(cfg, dtype="fp32"), params, torch.from_numpy(sb["cond"]), torch)
+        c1 = job.cond(0, 1).cpu()
+        if tiled:
+            c1 = c1[..., :cfg["image_size"] // 16, :cfg["image_size"] // 16].contiguous()
+        line["cpu_baseline"] = cpu_baseline(dict(cfg, dtype="fp32"), run, job.params, c1, torch)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -36,24 +36,15 @@ def tile_plan(h: int, w: int, tile: int, overlap: int) -> tuple[list[int], list[
 
 
 @torch.no_grad()
-def sample_tiled(sampler, cond: torch.Tensor, steps: int, *, overlap: int = 64, seed: int = 0, first_image: int = 0,
-                 tiles_per_call: int = 16) -> torch.Tensor:
-    """cond [B, Cc, hc, wc] -> x_0 [B, C, 16*hc, 16*wc] decoded through the sampler's (tile-sized) UNet."""
-    with torch.cuda.device(sampler.unet.device):
-        return _sample_tiled(sampler, cond, steps, overlap, seed, first_image, tiles_per_call)
-
-
-def _sample_tiled(sampler, cond, steps, overlap, seed, first_image, tiles_per_call):
-    net, cfg = sampler.unet, sampler.unet.cfg
-    if sampler.method != "ddim" or cfg["cond_mode"] != "concat":
-        raise ValueError("tiled decode is defined for the deterministic DDIM sampler with concat conditioning")
-    dev = net.device
+def tile_batch(net, cond: torch.Tensor, overlap: int, seed: int, first_image: int):
+    """The tiles of `cond`'s images as ordinary batch entries: (conds [B*ny*nx, Cc, T/16, T/16], x_T [B*ny*nx, C, T, T],
+    ys, xs).  x_T tiles are crops of ONE noise field per image (generator stream keyed by the global image index)."""
+    cfg, dev = net.cfg, net.device
     B, Cc, hc, wc = cond.shape
     T, C = cfg["image_size"], cfg["in_channels"]
     H, W = hc * COND_STRIDE, wc * COND_STRIDE
     ys, xs = tile_plan(H, W, T, overlap)
     cond = cond.to(dev, torch.float32)
-    # one noise field per image, cropped per tile
     full = torch.zeros(B, H, W, 4, device=dev)
     ops.gauss_fill(full, C, seed, first_image, STREAM_XT)
     full = full[..., :C].permute(0, 3, 1, 2)
@@ -64,14 +55,33 @@ def _sample_tiled(sampler, cond, steps, overlap, seed, first_image, tiles_per_ca
             for x in xs:
                 conds.append(cond[b, :, y // COND_STRIDE:y // COND_STRIDE + ct, x // COND_STRIDE:x // COND_STRIDE + ct])
                 xts.append(full[b, :, y:y + T, x:x + T])
-    conds, xts = torch.stack(conds).contiguous(), torch.stack(xts).contiguous()
-    outs = []
-    for i in range(0, conds.shape[0], tiles_per_call):
-        outs.append(sampler.sample(conds[i:i + tiles_per_call], steps, seed=seed, x_T=xts[i:i + tiles_per_call]))
-    tiles = torch.cat(outs).contiguous()
+    return torch.stack(conds).contiguous(), torch.stack(xts).contiguous(), ys, xs
+
+
+@torch.no_grad()
+def blend_tiles(net, tiles: torch.Tensor, B: int, ys: list[int], xs: list[int], H: int, W: int) -> torch.Tensor:
+    """tiles [B*ny*nx, C, T, T] (decoded, device) -> [B, C, H, W] with separable linear ramps (cdx_tile_blend_f32)."""
+    dev, T, C = net.device, net.cfg["image_size"], net.cfg["in_channels"]
+    tiles = tiles.contiguous()
     out = torch.empty(B, C, H, W, device=dev)
     y0 = torch.tensor(ys, dtype=torch.int32, device=dev)
     x0 = torch.tensor(xs, dtype=torch.int32, device=dev)
     a = _abi.TileBlendArgs(tiles.data_ptr(), B, C, T, len(ys), len(xs), y0.data_ptr(), x0.data_ptr(), H, W, out.data_ptr())
     _abi.call("tile_blend_f32", a, None, 0, torch.cuda.current_stream(dev).cuda_stream)
     return out
+
+
+@torch.no_grad()
+def sample_tiled(sampler, cond: torch.Tensor, steps: int, *, overlap: int = 64, seed: int = 0, first_image: int = 0,
+                 tiles_per_call: int = 16) -> torch.Tensor:
+    """cond [B, Cc, hc, wc] -> x_0 [B, C, 16*hc, 16*wc] decoded through the sampler's (tile-sized) UNet."""
+    net, cfg = sampler.unet, sampler.unet.cfg
+    if sampler.method != "ddim" or cfg["cond_mode"] != "concat":
+        raise ValueError("tiled decode is defined for the deterministic DDIM sampler with concat conditioning")
+    with torch.cuda.device(net.device):
+        B, _, hc, wc = cond.shape
+        conds, xts, ys, xs = tile_batch(net, cond, overlap, seed, first_image)
+        outs = []
+        for i in range(0, conds.shape[0], tiles_per_call):
+            outs.append(sampler.sample(conds[i:i + tiles_per_call], steps, seed=seed, x_T=xts[i:i + tiles_per_call]))
+        return blend_tiles(net, torch.cat(outs), B, ys, xs, hc * COND_STRIDE, wc * COND_STRIDE)
