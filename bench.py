@@ -106,6 +106,10 @@ def kernel_model(variant) -> dict:
         # Winograd F(2x2,3x3): 16 transform-domain multiply-adds per 2x2 output tile where the direct algorithm needs 36
         return {"name": "conv_wino8_kernel<WinoCfg<2,0>> (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
                 "executed_per_algorithmic": 1.0 / 2.25, "peak": FP32_MFMA_PEAK_TFLOPS, "wino": True, "flops_per_mfma_cycle": 64.0}
+    if tile.startswith("split"):
+        # float32 product on the fp16 matrix pipe: hi*hi + lo*hi + hi*lo = 3 fp16 MFMA FLOPs per algorithmic FLOP
+        return {"name": "conv16_kernel<Conv16Cfg<..., SPLIT>> (f32 conv as 3 x v_mfma_f32_32x32x16_f16 on hi|lo split operands)",
+                "executed_per_algorithmic": 3.0, "peak": FP16_MFMA_PEAK_TFLOPS, "wino": False, "flops_per_mfma_cycle": 1024.0}
     if tile.startswith("f16"):
         return {"name": "conv16_kernel<Conv16Cfg> (v_mfma_f32_32x32x16_f16)", "executed_per_algorithmic": 1.0,
                 "peak": FP16_MFMA_PEAK_TFLOPS, "wino": False, "flops_per_mfma_cycle": 1024.0}
@@ -250,6 +254,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sample-call", action="store_true", help="skip the extra timing of one complete Sampler.sample()")
+    ap.add_argument("--no-split", action="store_true", help="A/B: float32 layers on the f32-input MFMA kernels only (no fp16 hi|lo split tile)")
     ap.add_argument("--details", action="store_true", help="print the per-variant conv table to stderr")
     args = ap.parse_args()
 
@@ -277,7 +282,7 @@ def main():
     tiles_per_image = len(cdx.tile_origins(run["image"], cfg["image_size"], run["overlap"])) ** 2 if tiled else 1
     images_per_gpu = 1 if tiled else B            # cfg5: the step loop runs B TILES; sample_call decodes one whole image
     job = cdx.shard.ShardJob(images_per_gpu * world, args.config, rank=rank, world=world, device=f"cuda:{local}",
-                             images_per_call=images_per_gpu)
+                             images_per_call=images_per_gpu, unet_kw={"split": False} if args.no_split else None)
     sampler, net = job.sampler, job.sampler.unet
     sync = torch.cuda.synchronize
 
@@ -309,6 +314,10 @@ def main():
         "value": round(images_per_s, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16" if cfg["dtype"] == "fp16" else "f32", "data": "synthetic",
+        "arithmetic": ("fp16 storage, v_mfma_f32_32x32x16_f16, float32 accumulate" if cfg["dtype"] == "fp16" else
+                       "float32 storage and results; layers >= 32 px wide: float32 products as 3 fp16 MFMAs on hi|lo split operands, "
+                       "float32 accumulate (CDX_TILE_SPLIT); other layers: v_mfma_f32_32x32x2_f32" if not args.no_split else
+                       "float32 storage, v_mfma_f32_32x32x2_f32 (direct + Winograd F(2x2,3x3))"),
         "config": {"workload": (f"BASELINE.json configs[1]: 256x256x3, 128-ch UNet (channel_mult 1,1,2,2,4,4; "
                                 f"self-attn at 16^2), {run['steps']}-step {run['method'].upper()}, batch {B} per GPU, "
                                 f"seeded random weights (cdx.init_params seed 0)") if args.config in ("cfg2", "cfg3") else

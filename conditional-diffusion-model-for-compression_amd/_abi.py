@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/conv_bench.py only); the product always loads libcdx.so.
 LIB_PATH = os.path.join(_HERE, "libcdx_tune.so" if os.environ.get("CDX_TUNE") == "1" else "libcdx.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 CONV_UPSAMPLE2X, CONV_GN, CONV_SILU = 1, 2, 4
 LINEAR_SILU_IN = 1
 CONV_KC = 32
@@ -27,7 +27,8 @@ class ConvArgs(C.Structure):
                 ("batch", _i), ("hin", _i), ("win", _i), ("hout", _i), ("wout", _i),
                 ("cout", _i), ("ksize", _i), ("stride", _i), ("flags", _i),
                 ("wpacked", _f), ("bias", _f), ("gn_scale", _f), ("gn_shift", _f),
-                ("temb", _f), ("temb_ld", _i), ("residual", _f), ("out", _f), ("out_ld", _i), ("wpacked_wino", _f), ("stats_out", _f)]
+                ("temb", _f), ("temb_ld", _i), ("residual", _f), ("out", _f), ("out_ld", _i), ("wpacked_wino", _f), ("stats_out", _f),
+                ("wpacked_split", _f), ("wsplit_unscale", C.c_float)]
 
 
 class ConvF16Args(C.Structure):
@@ -112,12 +113,13 @@ OPS = {
 }
 
 # every exported symbol include/cdx.h declares (checked by tests/test_abi.py without a GPU)
-TILE_NAMES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "64x128", 4: "64x64", 5: "S32x32", 6: "S64x32", 7: "wino128x128", 8: "small256x4", 9: "small256x4valu", 10: "cin8_128x128"}
+TILE_NAMES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "64x128", 4: "64x64", 5: "S32x32", 6: "S64x32", 7: "wino128x128", 8: "small256x4", 9: "small256x4valu", 10: "cin8_128x128", 11: "split128x128"}
 
 EXPORTS = (["cdx_abi_version", "cdx_strerror", "cdx_launch_count",
             "cdx_conv_packed_floats", "cdx_conv_pack_weights_f32", "cdx_conv_select_tile", "cdx_conv_f32_tile",
             "cdx_conv_stats_slots", "cdx_conv_wino_packed_floats", "cdx_conv_pack_weights_wino_f32",
-            "cdx_conv_f16_stats_slots", "cdx_conv_f16_packed_halves", "cdx_conv_pack_weights_f16"]
+            "cdx_conv_f16_stats_slots", "cdx_conv_f16_packed_halves", "cdx_conv_pack_weights_f16",
+            "cdx_conv_split_packed_halves", "cdx_conv_pack_weights_split_f16"]
            + [f"cdx_{op}" for op in OPS] + [f"cdx_{op}_workspace" for op in OPS])
 
 _lib = None
@@ -156,6 +158,10 @@ def lib() -> C.CDLL:
     L.cdx_conv_f16_packed_halves.argtypes = [_i, _i, _i, _i]
     L.cdx_conv_pack_weights_f16.restype = C.c_int
     L.cdx_conv_pack_weights_f16.argtypes = [_f, _i, _i, _i, _i, _f]
+    L.cdx_conv_split_packed_halves.restype = C.c_size_t
+    L.cdx_conv_split_packed_halves.argtypes = [_i, _i, _i, _i]
+    L.cdx_conv_pack_weights_split_f16.restype = C.c_int
+    L.cdx_conv_pack_weights_split_f16.argtypes = [_f, _i, _i, _i, _i, _f, C.POINTER(C.c_float)]
     L.cdx_conv_select_tile.restype = C.c_int
     L.cdx_conv_select_tile.argtypes = [C.POINTER(ConvArgs)]
     L.cdx_conv_stats_slots.restype = C.c_int32
@@ -228,3 +234,19 @@ def pack_conv_weights_f16(w_oihw, c0: int, c1: int):
     out = np.empty(n, np.float16)
     check(lib().cdx_conv_pack_weights_f16(w.ctypes.data, c0, c1, cout, k, out.ctypes.data), "cdx_conv_pack_weights_f16")
     return out
+
+
+def pack_conv_weights_split(w_oihw, c0: int, c1: int):
+    """numpy OIHW float32 -> (fp16 hi|lo fragment image as numpy float16, unscale = 2^-s) for CDX_TILE_SPLIT (host)."""
+    import numpy as np
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    cout, cin, k, _ = w.shape
+    assert cin == c0 + c1
+    n = int(lib().cdx_conv_split_packed_halves(c0, c1, cout, k))
+    if n == 0:
+        raise CdxError("cdx_conv_split_packed_halves: bad arguments")
+    out = np.empty(n, np.float16)
+    un = C.c_float(0.0)
+    check(lib().cdx_conv_pack_weights_split_f16(w.ctypes.data, c0, c1, cout, k, out.ctypes.data, C.byref(un)),
+          "cdx_conv_pack_weights_split_f16")
+    return out, float(un.value)

@@ -8,6 +8,11 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
 
 using namespace cdx;
 
+namespace cdx {
+bool conv_split_ok(const cdx_conv_args* a);                       // conv16.hip
+int conv_split_launch(const cdx_conv_args* a, hipStream_t stream);
+}  // namespace cdx
+
 namespace {
 
 inline int chunks_of(int c) { return (c + CDX_CONV_KC - 1) / CDX_CONV_KC; }
@@ -101,6 +106,7 @@ Tile tile_of(int wcfg) {
         case WCFG_CIN8: return {wcfg, 128, 128, 1};    // 128x128 tile that multiplies only the first 8 channels of the chunk
         case WCFG_SMALL: return {wcfg, 256, 4, 1};     // 8 x 32 pixels, cout <= 4 (4x4x1 MFMA form)
         case WCFG_SMALL_VALU: return {wcfg, 256, 4, 1};   // same tile, vector-ALU form (scalar-cache weights)
+        case WCFG_SPLIT: return {wcfg, 128, 128, 1};      // fp16 matrix pipe, operands split hi/lo (conv16_kernel.h SPLIT)
         default: return {-1, 0, 0, 0};
     }
 }
@@ -135,6 +141,10 @@ Tile select_tile(const cdx_conv_args* a) {
         // 8^2: 128x128 14 TF, 128x32 25, S32x32 50;  16^2: 128x128 48 TF, 128x64 65, S32x32 62
         t = tile_of(hw <= 64 ? WCFG_S32 : hw <= 256 ? WCFG_2x2x2 : t.wcfg);
     }
+    // Layers at >= 32 pixels wide: the float32 product on the FP16 matrix pipe with split operands (3 MFMAs of 32 cycles
+    // per 16 channels against 8 x 64 for the f32-input MFMA): same float32-level error, 2.4x less matrix-pipe time than
+    // even the Winograd kernel.  Needs the wpacked_split image; otherwise the float32-MFMA kernels below are used.
+    if (conv_split_ok(a)) return tile_of(WCFG_SPLIT);
     if (a->ksize == 3) {
         if (hw <= kSplitKMaxPixels) t = tile_of(a->stride == 1 && hw >= 256 ? WCFG_S64 : WCFG_S32);
         else if (cin8_ok(a)) t = tile_of(WCFG_CIN8);
@@ -145,8 +155,9 @@ Tile select_tile(const cdx_conv_args* a) {
 }
 
 bool tile_allowed(const cdx_conv_args* a, int wcfg) {
-    if (a->ksize == 1) return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1 || ((wcfg == WCFG_S32 || wcfg == WCFG_S64) && a->wout < 32);
     if (a->stride == 2) return wcfg == WCFG_1x4x2 || wcfg == WCFG_2x2x1 || wcfg == WCFG_S32;
+    if (wcfg == WCFG_SPLIT) return conv_split_ok(a);
+    if (a->ksize == 1) return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1 || ((wcfg == WCFG_S32 || wcfg == WCFG_S64) && a->wout < 32);
     if (wcfg == WCFG_WINO) return wino_ok(a);
     if (wcfg == WCFG_CIN8) return cin8_ok(a);
     if (wcfg == WCFG_SMALL || wcfg == WCFG_SMALL_VALU) return small_ok(a);
@@ -169,6 +180,7 @@ int validate(const cdx_conv_args* a) {
     CDX_REQUIRE(a->out_ld >= a->cout);
     CDX_REQUIRE(aligned16(a->src0) && aligned16(a->src1) && aligned16(a->wpacked));
     if (a->flags & CDX_CONV_GN) CDX_REQUIRE(a->gn_scale && a->gn_shift && aligned16(a->gn_scale) && aligned16(a->gn_shift));
+    if (a->wpacked_split) CDX_REQUIRE(aligned16(a->wpacked_split) && a->wsplit_unscale > 0.f);
     if (a->temb) CDX_REQUIRE(a->temb_ld >= a->cout);
     if (a->stats_out) CDX_REQUIRE((a->cout % 4) == 0 && (a->out_ld % 4) == 0);   // sums are produced by the packed epilogue
     if (a->residual && (a->cout % 4) == 0) CDX_REQUIRE(aligned16(a->residual));
@@ -239,6 +251,7 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
 
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (t.wcfg == WCFG_SPLIT) return conv_split_launch(a, st);
     if (t.wcfg == WCFG_WINO || (experimental && tile >= 31)) {
         if (!wino_ok(a)) return CDX_ENOTSUP;
         p.w = a->wpacked_wino;

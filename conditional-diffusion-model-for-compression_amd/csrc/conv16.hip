@@ -1,4 +1,5 @@
 // Host side + instantiations of the fp16-storage convolution (conv16_kernel.h).
+#include <math.h>
 #include <string.h>
 
 #include "conv16_kernel.h"
@@ -122,12 +123,101 @@ extern "C" int cdx_conv_f16(const cdx_conv_f16_args* a, void*, size_t, cdx_strea
     p.gn = (a->flags & CDX_CONV_GN) ? 1 : 0;
     p.silu = (a->flags & CDX_CONV_SILU) ? 1 : 0;
     p.abl = (a->flags >> 8) & 7;
+    p.wunscale = 1.f;
     p.w = reinterpret_cast<const _Float16*>(a->wpacked);
     p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift; p.temb = a->temb; p.temb_ld = a->temb_ld;
-    p.residual = reinterpret_cast<const _Float16*>(a->residual);
+    p.residual = a->residual;
     p.out = a->out; p.out_f32 = a->out_is_f32 ? 1 : 0; p.out_ld = a->out_ld; p.stats = a->stats_out;
     int logtw;
     tile_grid(a, logtw, p.tiles_x, p.tiles_y);
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
     return conv16_dispatch(a->ksize, a->stride, logtw, p, static_cast<hipStream_t>(stream));
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// SPLIT mode (conv16_kernel.h): float32 convolution on the fp16 matrix pipe, reached through cdx_conv_f32 (conv.hip).
+// Host: fp16 hi/lo fragment image of the weights, pre-scaled by 2^s with s chosen per layer so that max |w| 2^s lies in
+// [2^13, 2^14): hi = fp16(w 2^s), lo = fp16(w 2^s - hi) are then normal numbers for every weight above 2^-27 of the
+// largest.  Layout [ntile][chunk][tap][j = 0..1][plane = hi, lo][lane][8 halves], + 16 KiB zero pad.
+extern "C" size_t cdx_conv_split_packed_halves(int32_t c0, int32_t c1, int32_t cout, int32_t ksize) {
+    if (c0 <= 0 || c1 < 0 || cout <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    const size_t ntiles = (cout + 31) / 32, nch = chunks_of(c0) + chunks_of(c1);
+    return ntiles * nch * ksize * ksize * 2048 + 8192;
+}
+
+extern "C" int cdx_conv_pack_weights_split_f16(const float* w, int32_t c0, int32_t c1, int32_t cout, int32_t ksize,
+                                               cdx_half* packed, float* unscale) {
+    CDX_REQUIRE(w && packed && unscale && c0 > 0 && c1 >= 0 && cout > 0 && (ksize == 1 || ksize == 3));
+    const int taps = ksize * ksize, ctot = c0 + c1;
+    const int nch0 = chunks_of(c0), nch = nch0 + chunks_of(c1), ntiles = (cout + 31) / 32;
+    float wmax = 0.f;
+    for (size_t i = 0; i < (size_t)cout * ctot * taps; ++i) {
+        CDX_REQUIRE(w[i] == w[i] && w[i] - w[i] == 0.f);      // finite
+        wmax = fmaxf(wmax, fabsf(w[i]));
+    }
+    int e = 0;
+    if (wmax > 0.f) {
+        frexpf(wmax, &e);                  // wmax = m 2^e, m in [0.5, 1)
+        e = 14 - e;                        // wmax 2^e in [2^13, 2^14)
+        if (e > 100) e = 100;
+        if (e < -100) e = -100;
+    }
+    const float sc = ldexpf(1.f, e);
+    *unscale = ldexpf(1.f, -e);
+    _Float16* o = reinterpret_cast<_Float16*>(packed);
+    for (int nt = 0; nt < ntiles; ++nt)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int j = 0; j < 2; ++j)
+                    for (int plane = 0; plane < 2; ++plane)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int k = 0; k < 8; ++k) {
+                                const int n = nt * 32 + (lane & 31);
+                                const int cl = (ch < nch0 ? ch : ch - nch0) * 32 + 16 * j + 8 * (lane >> 5) + k;
+                                const int csrc = ch < nch0 ? c0 : c1;
+                                float v = 0.f;
+                                if (n < cout && cl < csrc) v = w[((size_t)n * ctot + (ch < nch0 ? 0 : c0) + cl) * taps + tap] * sc;
+                                const _Float16 hi = (_Float16)v;
+                                *o++ = plane == 0 ? hi : (_Float16)(v - (float)hi);
+                            }
+    memset(o, 0, 8192 * sizeof(_Float16));
+    return CDX_OK;
+}
+
+namespace cdx {
+// Is this cdx_conv_f32 launch one the SPLIT kernel is built for?  (conv.hip asks before choosing the tile.)
+bool conv_split_ok(const cdx_conv_args* a) {
+    if (!a->wpacked_split || !aligned16(a->wpacked_split) || !(a->wsplit_unscale > 0.f)) return false;
+    if (a->stride != 1 || a->wout < 32 || a->cout <= 4) return false;
+    if ((a->out_ld % 4) != 0 || a->out_ld < ((a->cout + 3) & ~3)) return false;      // outputs move as 4-channel vectors
+    if ((a->residual || a->stats_out) && (a->cout % 4) != 0) return false;
+    return true;
+}
+
+int conv_split_launch(const cdx_conv_args* a, hipStream_t stream) {
+    Conv16Params p;
+    p.src[0] = a->src0;
+    p.src[1] = a->src1 ? a->src1 : a->src0;
+    p.csrc[0] = a->c0;
+    p.csrc[1] = a->c1 ? a->c1 : a->c0;
+    p.src_f32 = 1;
+    p.nchunk0 = chunks_of(a->c0);
+    p.nchunks = p.nchunk0 + chunks_of(a->c1);
+    p.ctot = a->c0 + a->c1;
+    p.B = a->batch; p.Hin = a->hin; p.Win = a->win; p.Hout = a->hout; p.Wout = a->wout; p.Cout = a->cout;
+    p.ups = (a->flags & CDX_CONV_UPSAMPLE2X) ? 1 : 0;
+    p.gn = (a->flags & CDX_CONV_GN) ? 1 : 0;
+    p.silu = (a->flags & CDX_CONV_SILU) ? 1 : 0;
+    p.abl = 0;
+    p.wunscale = a->wsplit_unscale;
+    p.w = reinterpret_cast<const _Float16*>(a->wpacked_split);
+    p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift; p.temb = a->temb; p.temb_ld = a->temb_ld;
+    p.residual = a->residual;
+    p.out = a->out; p.out_f32 = 1; p.out_ld = a->out_ld; p.stats = a->stats_out;
+    p.tiles_x = ceil_div(a->wout, 32);
+    p.tiles_y = ceil_div(a->hout, 4);
+    CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
+    if (a->ksize == 3) return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 1>>(p, stream);
+    return conv16_launch<Conv16Cfg<1, 1, 5, 4, 3, 0, 1>>(p, stream);
+}
+}  // namespace cdx

@@ -14,6 +14,16 @@
 //   * GroupNorm statistics are taken from the fp32 accumulators BEFORE rounding (GN stays fp32).
 // The kernel is no longer MFMA-bound (36.9k -> 2.3k MFMA cycles per chunk): the staging VALU, LDS reads and the
 // L2 weight stream set its speed.
+//
+// SPLIT = 1: the SAME kernel computes a FLOAT32 convolution on the fp16 matrix pipe (cdx_conv_f32's "split" tile).
+// Every float32 operand is split while staging into hi = fp16(v) and lo = fp16(v - hi) (v = hi + lo to ~2^-24 |v|; the
+// weights are pre-scaled by a per-layer power of two on the host so that their lo parts are normal fp16 numbers), and
+// each product block is three MFMAs: hi*hi + lo*hi + hi*lo, accumulated in float32 (the dropped lo*lo term is
+// <= 2^-22 of the product).  Measured error vs float64: the same as the float32-MFMA kernels' (tests: unchanged
+// tolerances).  v_mfma_f32_32x32x16_f16 retires 16 channels in 32 cycles where v_mfma_f32_32x32x2_f32 needs 8 x 64:
+// 3 x 32 = 96 cycles against 512 (direct) or 228 (Winograd F(2x2,3x3)) -- and unlike the f32-input MFMA it leaves
+// the vector ALU free for the staging work.  LDS image: per pixel 32 hi halves | 32 lo halves | 16 B pad = 144 B (the
+// float32 kernels' conflict-free stride); sources, residual and output float32; GroupNorm sums float64 as everywhere.
 #pragma once
 #include <hip/hip_fp16.h>
 
@@ -33,13 +43,14 @@ struct Conv16Params {
     int B, Hin, Win, Hout, Wout, Cout;
     int ups, gn, silu;
     int abl;         // timing ablation selector (diagnostics)
+    float wunscale;  // SPLIT: 2^-s, undoes the host's power-of-two weight scaling (exact); 1 otherwise
     const _Float16* w;
     const float* bias;
     const float* gscale;
     const float* gshift;
     const float* temb;
     int temb_ld;
-    const _Float16* residual;
+    const void* residual;   // fp16 (fp32 in SPLIT mode)
     void* out;
     int out_f32;
     int out_ld;
@@ -48,10 +59,11 @@ struct Conv16Params {
 };
 
 // ABL: timing-only ablations (wrong results): 1 = no epilogue, 2 = stage only the first chunk, 4 = no weight refills
-template <int KS_, int STRIDE_, int LOGTW_, int MT_, int PF_ = 3, int ABL_ = 0>
+template <int KS_, int STRIDE_, int LOGTW_, int MT_, int PF_ = 3, int ABL_ = 0, int SPLIT_ = 0>
 struct Conv16Cfg {
-    static constexpr int KS = KS_, STRIDE = STRIDE_, LOGTW = LOGTW_, MT = MT_, PF = PF_, ABL = ABL_;
-    static constexpr int KC = 32, PSH = KC + 8;                    // pixel stride in halves
+    static constexpr int KS = KS_, STRIDE = STRIDE_, LOGTW = LOGTW_, MT = MT_, PF = PF_, ABL = ABL_, SPLIT = SPLIT_;
+    static constexpr int PLANES = SPLIT ? 2 : 1;                   // hi | lo
+    static constexpr int KC = 32, PSH = KC * PLANES + 8;           // pixel stride in halves (80 B / 144 B)
     static constexpr int TAPS = KS * KS, PAD = KS / 2;
     static constexpr int TW = 1 << LOGTW;
     static constexpr int BM = MT * 32, BN = 128;
@@ -156,15 +168,22 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
             const int hp = i * 64 + pl;
             const int hy = hp / C::HW, hx = hp - hy * C::HW;
             const bool ok = cvalid && ((vmask >> i) & 1u);
-            f16x8 o;
+            f16x8 o, ol;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float v = pre[i][e];
                 if (p.gn) v = fmaf(v, gsc[e >> 2][e & 3], gsh[e >> 2][e & 3]);
                 if (p.silu) v = silu16_f(v);
-                o[e] = (_Float16)(ok ? v : 0.f);
+                if constexpr (C::SPLIT) {
+                    v = ok ? __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f) : 0.f;      // saturate instead of inf
+                    o[e] = (_Float16)v;
+                    ol[e] = (_Float16)(v - (float)o[e]);                               // exact difference, rounded once
+                } else o[e] = (_Float16)(ok ? v : 0.f);
             }
-            if (hp < C::NPIX) *reinterpret_cast<f16x8*>(&lds[hy * RSH + hx * PSH + q * 8]) = o;
+            if (hp < C::NPIX) {
+                *reinterpret_cast<f16x8*>(&lds[hy * RSH + hx * PSH + q * 8]) = o;
+                if constexpr (C::SPLIT) *reinterpret_cast<f16x8*>(&lds[hy * RSH + hx * PSH + KC + q * 8]) = ol;
+            }
         }
     };
 
@@ -173,8 +192,9 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     const int a_base = ((li >> C::LOGTW) * C::STRIDE) * RSH + ((li & (C::TW - 1)) * C::STRIDE) * PSH + lh * 8;
     const int ntile = blockIdx.y * 4 + wn;
     const bool nvalid = ntile * 32 < p.Cout;
-    // packed weights: [ntile][chunk][tap][j = 0..1][lane][8 halves] -> one group = 512 halves (1 KiB)
-    const _Float16* __restrict__ wp = p.w + ((size_t)(nvalid ? ntile : 0) * p.nchunks * TAPS) * 1024 + lane * 8;
+    // packed weights: [ntile][chunk][tap][j = 0..1][plane][lane][8 halves] -> one group = GH halves (1 KiB per plane)
+    constexpr int GH = 512 * C::PLANES;
+    const _Float16* __restrict__ wp = p.w + ((size_t)(nvalid ? ntile : 0) * p.nchunks * TAPS) * (2 * GH) + lane * 8;
 
     f32x16 acc[MT];
 #pragma unroll
@@ -182,9 +202,11 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    f16x8 ring[PF];
+    f16x8 ring[PF][C::PLANES];
 #pragma unroll
-    for (int j = 0; j < PF; ++j) ring[j] = *reinterpret_cast<const f16x8*>(wp + j * 512);
+    for (int j = 0; j < PF; ++j)
+#pragma unroll
+        for (int pl_ = 0; pl_ < C::PLANES; ++pl_) ring[j][pl_] = *reinterpret_cast<const f16x8*>(wp + j * GH + pl_ * 512);
 
     // packed-epilogue layout (see below)
     using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
@@ -212,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
             }
         }
         if (nvalid) {
-            const _Float16* __restrict__ wc = wp + (size_t)chunk * (TAPS * 1024);
+            const _Float16* __restrict__ wc = wp + (size_t)chunk * (TAPS * 2 * GH);
 #pragma unroll
             for (int g = 0; g < GPC; ++g) {
                 if (GPC > 2 && more) {
@@ -223,15 +245,29 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
                 int ab = a_base;
                 asm volatile("" : "+v"(ab));                 // no cross-tap CSE of LDS reads (see conv_kernel.h)
                 __builtin_assume((ab & 7) == 0);
-                f16x8 a[MT];
+                f16x8 a[MT], al[MT];
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
+                for (int t = 0; t < MT; ++t) {
                     a[t] = *reinterpret_cast<const f16x8*>(&lds[ab + (t * C::RPM * C::STRIDE + ky) * RSH + kx * PSH + j * 16]);
-                const f16x8 bq = ring[g % PF];
-                if constexpr (!(C::ABL & 4))
-                    ring[g % PF] = *reinterpret_cast<const f16x8*>(wc + (size_t)(g + PF) * 512);   // wraps into the next chunk / tail pad
+                    if constexpr (C::SPLIT)
+                        al[t] = *reinterpret_cast<const f16x8*>(&lds[ab + (t * C::RPM * C::STRIDE + ky) * RSH + kx * PSH + KC + j * 16]);
+                }
+                const f16x8 bq = ring[g % PF][0];
+                f16x8 bl;
+                if constexpr (C::SPLIT) bl = ring[g % PF][1];
+                if constexpr (!(C::ABL & 4)) {
+#pragma unroll
+                    for (int pl_ = 0; pl_ < C::PLANES; ++pl_)      // wraps into the next chunk / tail pad
+                        ring[g % PF][pl_] = *reinterpret_cast<const f16x8*>(wc + (size_t)(g + PF) * GH + pl_ * 512);
+                }
 #pragma unroll
                 for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t], bq, acc[t], 0, 0, 0);
+                if constexpr (C::SPLIT) {      // the two cross terms (lo*lo, <= 2^-22 of the product, is dropped)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bq, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t], bl, acc[t], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -259,23 +295,29 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     // registers, so every lane stores / loads 4 consecutive channels of ONE pixel (8 B fp16, 16 B fp32) -- 4x fewer,
     // 4x wider memory instructions than the accumulator layout allows.  GroupNorm sums are reduced in that layout.
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    const float un = p.wunscale;            // SPLIT: undo the weights' power-of-two scaling (exact); 1 otherwise
     auto epilogue = [&](auto has_res, auto has_stats, auto out32) __attribute__((always_inline)) {
-        f16x4 rv[MT][4];
-        if constexpr (decltype(has_res)::value) {      // one batch of 8-byte loads (a load in the last chunk instead
+        using res_t = std::conditional_t<C::SPLIT != 0, f32x4, f16x4>;      // residual: float32 in SPLIT mode
+        using rel_t = std::conditional_t<C::SPLIT != 0, float, _Float16>;
+        res_t rv[MT][4];
+        if constexpr (decltype(has_res)::value) {      // one batch of 8/16-byte loads (a load in the last chunk instead
 #pragma unroll                                          // would queue the weight ring behind HBM misses: vmcnt is in-order)
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int m = t * 32 + 8 * k + q4 + 4 * lh;
                     const int oy = min(oy0 + (m >> C::LOGTW), p.Hout - 1), ox = min(ox0 + (m & (C::TW - 1)), p.Wout - 1);
-                    rv[t][k] = *reinterpret_cast<const f16x4*>(p.residual + (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + (quad_ok ? cq : 0));
+                    rv[t][k] = *reinterpret_cast<const res_t*>(static_cast<const rel_t*>(p.residual) +
+                                                               (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + (quad_ok ? cq : 0));
                 }
         }
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float x[4] = {acc[t][4 * k] + add, acc[t][4 * k + 1] + add, acc[t][4 * k + 2] + add, acc[t][4 * k + 3] + add};
+                float x[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[c] = C::SPLIT ? fmaf(acc[t][4 * k + c], un, add) : acc[t][4 * k + c] + add;
                 quad_transpose(x, q4);                        // now: pixel 8k + q4 (+4 lh) of tile t, channels cq..cq+3
                 const int m = t * 32 + 8 * k + q4 + 4 * lh;
                 const int oy = oy0 + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
@@ -305,7 +347,13 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    if (p.out_f32) {
+    if constexpr (C::SPLIT) {          // float32 in, float32 out
+        if (p.residual) {
+            if (p.stats) epilogue(T_{}, T_{}, T_{}); else epilogue(T_{}, F_{}, T_{});
+        } else {
+            if (p.stats) epilogue(F_{}, T_{}, T_{}); else epilogue(F_{}, F_{}, T_{});
+        }
+    } else if (p.out_f32) {
         if (p.residual) epilogue(T_{}, F_{}, T_{}); else epilogue(F_{}, F_{}, T_{});
     } else if (p.residual) {
         if (p.stats) epilogue(T_{}, T_{}, F_{}); else epilogue(T_{}, F_{}, F_{});

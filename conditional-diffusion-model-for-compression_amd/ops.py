@@ -41,7 +41,7 @@ def _ws(nbytes: int, device):
 class PackedConv:
     """Device-resident packed weights of one convolution (built once per layer)."""
 
-    def __init__(self, w_oihw, bias, c0: int, c1: int = 0, device="cuda", winograd: bool = True):
+    def __init__(self, w_oihw, bias, c0: int, c1: int = 0, device="cuda", winograd: bool = True, split: bool = True):
         import numpy as np
         w = np.asarray(w_oihw, dtype=np.float32)
         self.cout, cin, self.ksize, _ = w.shape
@@ -52,6 +52,11 @@ class PackedConv:
         self.w_wino = None
         if winograd and self.ksize == 3:
             self.w_wino = torch.from_numpy(_abi.pack_conv_weights_wino(w, c0, c1)).to(device)
+        # ... and the fp16 hi|lo split image (float32 products on the fp16 matrix pipe, cdx.h CDX_TILE_SPLIT)
+        self.w_split, self.split_unscale = None, 0.0
+        if split:
+            img, self.split_unscale = _abi.pack_conv_weights_split(w, c0, c1)
+            self.w_split = torch.from_numpy(img).to(device)
         self.bias = None if bias is None else torch.as_tensor(np.asarray(bias, np.float32)).to(device)
 
 
@@ -133,6 +138,7 @@ def conv_args(pc: PackedConv, src0, src1, out, *, stride=1, upsample=False, gn=N
     a.cout, a.ksize, a.stride, a.flags = pc.cout, pc.ksize, stride, flags
     a.wpacked, a.bias = _ptr(pc.w), _ptr(pc.bias)
     a.wpacked_wino = _ptr(pc.w_wino)
+    a.wpacked_split, a.wsplit_unscale = _ptr(pc.w_split), pc.split_unscale
     if gn is not None:
         a.gn_scale, a.gn_shift = _ptr(gn[0]), _ptr(gn[1])
     if temb is not None:

@@ -69,11 +69,11 @@ def timed_region(fn, dist=None, sync=None) -> float:
     return elapsed
 
 
-def _hip_sampler(cfg: dict, run: dict, params: dict, device):
+def _hip_sampler(cfg: dict, run: dict, params: dict, device, **unet_kw):
     """The product sampler: HIP UNet + Sampler on `device` (raises without a GPU / libcdx.so: no CPU fallback)."""
     from .sampler import Sampler
     from .unet import UNet
-    return Sampler(UNet(cfg, params, device=device), method=run["method"])
+    return Sampler(UNet(cfg, params, device=device, **unet_kw), method=run["method"])
 
 
 class ShardJob:
@@ -86,7 +86,7 @@ class ShardJob:
 
     def __init__(self, total_images: int | None, cfg_name: str = "cfg2", *, rank: int = 0, world: int = 1, device=None,
                  seed: int = 0, images_per_call: int | None = None, steps: int | None = None, make_sampler=None,
-                 config: tuple[dict, dict] | None = None, params: dict | None = None):
+                 config: tuple[dict, dict] | None = None, params: dict | None = None, unet_kw: dict | None = None):
         from .config import named_config
         from .params import init_params
         self.cfg, self.run = config if config is not None else named_config(cfg_name)
@@ -98,7 +98,8 @@ class ShardJob:
         self.tiled = "image" in self.run
         self.device = device
         self.params = init_params(dict(self.cfg, dtype="fp32"), seed) if params is None else params
-        self.sampler = (make_sampler or _hip_sampler)(self.cfg, self.run, self.params, device)
+        self.sampler = (make_sampler(self.cfg, self.run, self.params, device) if make_sampler is not None else
+                        _hip_sampler(self.cfg, self.run, self.params, device, **(unet_kw or {})))
 
     # ---- inputs: synthetic, keyed by the GLOBAL image index (params.synthetic_batch) ----
     def inputs(self, first: int, count: int) -> dict:

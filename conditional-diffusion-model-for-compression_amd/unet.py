@@ -211,9 +211,10 @@ class UNet:
     """unet = UNet(cfg_dict[, params]); eps = unet.forward(x, t, cond)."""
 
     def __init__(self, cfg: dict, params: dict | None = None, *, seed: int = 0, device="cuda",
-                 fuse_gn_stats: bool = True):
+                 fuse_gn_stats: bool = True, split: bool = True):
         _abi.lib()   # fail loudly now if the extension is missing
         self.fuse_gn_stats = fuse_gn_stats   # False: every GroupNorm re-reads its input (cdx_gn_stats_f32)
+        self.split = split                   # float32 layers carry the fp16 hi|lo weight image (CDX_TILE_SPLIT); False: f32-MFMA kernels only
         self.half = validate_unet_config(cfg)["dtype"] == "fp16"
         if not torch.cuda.is_available():
             raise RuntimeError("UNet (HIP backend) needs a GPU; there is no CPU fallback in the product path")
@@ -252,14 +253,15 @@ class UNet:
                 for b in res_blocks:    # up-path ResBlocks read (x, skip) as two sources
                     if b.skip_ch and base in (b.name + ".conv1", b.name + ".skip"):
                         c0, c1 = b.cin - b.skip_ch, b.skip_ch
-                self.convs[base] = (ops.PackedConv16 if self.half else ops.PackedConv)(w, bias, c0, c1, self.device)
+                self.convs[base] = (ops.PackedConv16(w, bias, c0, c1, self.device) if self.half else
+                                    ops.PackedConv(w, bias, c0, c1, self.device, split=split))
             elif ".norm" in name or name.startswith("temb."):
                 self.dev[name] = up(P[name])
         for b in g.down + g.mid + g.up:
             if b.kind == "xattn":   # kv projection of the context tokens runs as a 1x1 convolution
                 w = P[b.name + ".kv.weight"]
                 self.convs[b.name + ".kv"] = (ops.PackedConv16 if self.half else ops.PackedConv)(
-                    w[:, :, None, None], P[b.name + ".kv.bias"], w.shape[1], 0, self.device)
+                    w[:, :, None, None], P[b.name + ".kv.bias"], w.shape[1], 0, self.device, **({} if self.half else {"split": split}))
         # all ResBlock temb projections as one [sum(cout), temb_dim] linear
         self.tproj_off, off = {}, 0
         for b in res_blocks:

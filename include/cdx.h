@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 2
+#define CDX_ABI_VERSION 3
 
 typedef void* cdx_stream_t; /* hipStream_t */
 
@@ -82,6 +82,12 @@ typedef struct cdx_conv_args {
     double* stats_out;     /* NULL, or [batch, cdx_conv_stats_slots(a), cout, 2]: per-slot (sum, sum of squares) of the
                               values stored to `out`, float64, for cdx_gn_finalize_f32 (GroupNorm of `out` without
                               re-reading it) */
+    const uint16_t* wpacked_split; /* NULL, or the cdx_conv_pack_weights_split_f16 image of the same weights (fp16 hi | lo
+                              planes, pre-scaled by a power of two): lets the library run stride-1 layers with
+                              wout >= 32 on the FP16 matrix pipe with split operands (hi*hi + lo*hi + hi*lo, float32
+                              accumulation) -- float32-level error, 3 MFMAs of 32 cycles per 16 channels where the
+                              f32-input MFMA needs 8 of 64 */
+    float wsplit_unscale;  /* the packer's `unscale` output (2^-s, exact); > 0 whenever wpacked_split is set */
 } cdx_conv_args;
 
 int cdx_conv_f32(const cdx_conv_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
@@ -104,7 +110,8 @@ enum {
     CDX_TILE_WINO = 7,    /* Winograd F(2x2,3x3), 128 pixels x 128 channels, needs wpacked_wino */
     CDX_TILE_SMALL = 8,   /* 3x3 stride 1, cout <= 4, width >= 32: 4x4x1-MFMA kernel, 256 pixels  */
     CDX_TILE_SMALL_VALU = 9, /* the same tile on the vector ALU (weights through the scalar cache)  */
-    CDX_TILE_CIN8 = 10    /* 3x3 stride 1, at most 8 input channels (conv_in): 128x128, first channel group only */
+    CDX_TILE_CIN8 = 10,   /* 3x3 stride 1, at most 8 input channels (conv_in): 128x128, first channel group only */
+    CDX_TILE_SPLIT = 11   /* stride 1, wout >= 32: 128x128 on v_mfma_f32_32x32x16_f16 with hi/lo split operands, needs wpacked_split */
 };
 int cdx_conv_select_tile(const cdx_conv_args* a);
 int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
@@ -123,6 +130,14 @@ int cdx_conv_pack_weights_f32(const float* w_oihw, int32_t c0, int32_t c1, int32
  *   = U[xi = 4*xiq + j][n = 32*ntile + (lane&31)][c = chunk_base + 8*s + 4*(lane>>5) + e],  + 16 KiB zero pad. */
 size_t cdx_conv_wino_packed_floats(int32_t c0, int32_t c1, int32_t cout);
 int cdx_conv_pack_weights_wino_f32(const float* w_oihw, int32_t c0, int32_t c1, int32_t cout, float* packed);
+/* HOST: split image of a float32 weight for CDX_TILE_SPLIT: w' = w 2^s with s chosen so that max |w'| lies in [2^13, 2^14);
+ * hi = fp16(w'), lo = fp16(w' - hi); *unscale = 2^-s (pass it as wsplit_unscale).  Layout (binary16 bit patterns):
+ *   [ntile][chunk][tap][j = 0..1][plane = hi, lo][lane = 0..63][k = 0..7]
+ *   = plane(W'[n = 32*ntile + (lane&31)][c = chunk_base + 16*j + 8*(lane>>5) + k][ky][kx]),  + 16 KiB zero pad.
+ * Non-finite weights are rejected (CDX_EINVAL). */
+size_t cdx_conv_split_packed_halves(int32_t c0, int32_t c1, int32_t cout, int32_t ksize);
+int cdx_conv_pack_weights_split_f16(const float* w_oihw, int32_t c0, int32_t c1, int32_t cout, int32_t ksize,
+                                    uint16_t* packed, float* unscale);
 
 /* ------------------------------------------------------------------------------------------
  * fp16-storage variants (BASELINE.json configs[4]; SURVEY.md 8a "_f16 variants"): activations and weights in IEEE

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(cdx._abi.EXPORTS), declared ^ set(cdx._abi.EXPORTS)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.cdx_abi_version() == 2
+    assert lib.cdx_abi_version() == 3
     assert b"workspace" in lib.cdx_strerror(-2) and lib.cdx_strerror(0) == b"ok"
 
 
@@ -92,6 +92,31 @@ def test_weight_packer_matches_documented_layout(lib, c0, c1, cout, k):
     want = ref_pack(w, c0, c1)
     assert got.shape == want.shape == (lib.cdx_conv_packed_floats(c0, c1, cout, k),)
     assert np.array_equal(got, want)
+
+
+def test_split_weight_packer_matches_documented_layout(lib):
+    """cdx_conv_pack_weights_split_f16: power-of-two scaling into [2^13, 2^14), hi = fp16(w'), lo = fp16(w' - hi), layout as
+    include/cdx.h documents; hi + lo reproduces w' to ~2^-22 relative."""
+    c0, c1, cout, k = 64, 32, 40, 3
+    w = (np.random.default_rng(5).standard_normal((cout, c0 + c1, k, k)) * 0.03).astype(np.float32)
+    img, un = cdx._abi.pack_conv_weights_split(w, c0, c1)
+    s = 1.0 / un
+    assert s == 2.0 ** round(np.log2(s)) and 2 ** 13 <= np.abs(w).max() * s < 2 ** 14
+    taps, nch0, nch1, ntiles = k * k, 2, 1, 2
+    body = img[:-8192].reshape(ntiles, nch0 + nch1, taps, 2, 2, 64, 8)
+    assert img.shape == (lib.cdx_conv_split_packed_halves(c0, c1, cout, k),) and not img[-8192:].any()
+    ws = (w * np.float32(s)).astype(np.float32)
+    for nt, ch, tap, j, lane, e in [(0, 0, 0, 0, 0, 0), (1, 2, 8, 1, 37, 5), (0, 1, 4, 1, 63, 7), (1, 0, 3, 0, 7, 2), (1, 1, 5, 0, 40, 0)]:
+        n = nt * 32 + (lane & 31)
+        cl = (ch if ch < nch0 else ch - nch0) * 32 + 16 * j + 8 * (lane >> 5) + e
+        c = cl if ch < nch0 else c0 + cl
+        want = ws[n, c].reshape(taps)[tap] if n < cout else np.float32(0)
+        hi, lo = body[nt, ch, tap, j, 0, lane, e], body[nt, ch, tap, j, 1, lane, e]
+        assert hi == np.float16(want) and lo == np.float16(want - np.float32(hi))
+        assert abs(float(hi) + float(lo) - float(want)) <= 2.0 ** -21 * abs(float(want))
+    bad = w.copy(); bad[0, 0, 0, 0] = np.inf
+    with pytest.raises(cdx._abi.CdxError):
+        cdx._abi.pack_conv_weights_split(bad, c0, c1)
 
 
 def test_hip_backend_fails_loudly_without_gpu():

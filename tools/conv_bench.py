@@ -38,6 +38,8 @@ flops = 2.0 * B * ho * wo * co * (c0 + c1) * k * k
 tiles = [int(t) for t in a.tiles.split(",")]
 L = _abi.lib()
 st = torch.cuda.current_stream().cuda_stream
+tiles = [t for t in tiles if L.cdx_conv_f32_tile(ctypes.byref(args), t, None, 0, st) == 0 or print(f"tile {t}: not built for this shape")]
+torch.cuda.synchronize()
 res = {t: [] for t in tiles}
 for r in range(a.rounds + 1):
     for t in tiles:
