@@ -10,7 +10,7 @@ using namespace cdx;
 
 namespace cdx {
 bool conv_split_ok(const cdx_conv_args* a);                       // conv16.hip
-int conv_split_launch(const cdx_conv_args* a, hipStream_t stream);
+int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant = 0);
 }  // namespace cdx
 
 namespace {
@@ -219,6 +219,11 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
     int rc = validate(a);
     if (rc) return rc;
 #ifdef CDX_TUNING
+    if (tile >= 60) {                       // split-tile ablations / variants (conv16.hip)
+        int rc60 = validate(a);
+        if (rc60) return rc60;
+        return conv_split_ok(a) ? conv_split_launch(a, static_cast<hipStream_t>(stream), tile - 60) : CDX_ENOTSUP;
+    }
     const bool experimental = tile >= 16;   // conv_exp.hip (16..30) / conv_wino.hip (31..): timing ablations (libcdx_tune.so)
 #else
     if (tile >= 16) return CDX_ENOTSUP;     // the shipped library carries no tuning / ablation instantiations

@@ -194,7 +194,7 @@ bool conv_split_ok(const cdx_conv_args* a) {
     return true;
 }
 
-int conv_split_launch(const cdx_conv_args* a, hipStream_t stream) {
+int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     Conv16Params p;
     p.src[0] = a->src0;
     p.src[1] = a->src1 ? a->src1 : a->src0;
@@ -217,6 +217,22 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream) {
     p.tiles_x = ceil_div(a->wout, 32);
     p.tiles_y = ceil_div(a->hout, 4);
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
+#ifdef CDX_TUNING
+    if (a->ksize == 3 && variant) {      // timing ablations / tuning variants (tools/conv_bench.py --tiles 60..)
+        switch (variant) {
+            case 1: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 1, 1>>(p, stream);      // no epilogue
+            case 2: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 2, 1>>(p, stream);      // stage first chunk only
+            case 3: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 3, 1>>(p, stream);
+            case 4: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 4, 1>>(p, stream);      // no weight refills
+            case 7: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 7, 1>>(p, stream);
+            case 8: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 8, 1>>(p, stream);      // no LDS operand reads
+            case 15: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 15, 1>>(p, stream);    // MFMA stream only
+            case 16: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 6, 0, 1>>(p, stream);     // ring depth 6
+            case 17: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 2, 0, 1>>(p, stream);     // ring depth 2
+            default: return CDX_ENOTSUP;
+        }
+    }
+#endif
     if (a->ksize == 3) return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 1>>(p, stream);
     return conv16_launch<Conv16Cfg<1, 1, 5, 4, 3, 0, 1>>(p, stream);
 }

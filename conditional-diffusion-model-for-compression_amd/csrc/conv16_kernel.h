@@ -58,7 +58,8 @@ struct Conv16Params {
     int tiles_x, tiles_y;
 };
 
-// ABL: timing-only ablations (wrong results): 1 = no epilogue, 2 = stage only the first chunk, 4 = no weight refills
+// ABL: timing-only ablations (wrong results; libcdx_tune.so only): 1 = no epilogue, 2 = stage only the first chunk,
+// 4 = no weight refills, 8 = no LDS operand reads (registers reused)
 template <int KS_, int STRIDE_, int LOGTW_, int MT_, int PF_ = 3, int ABL_ = 0, int SPLIT_ = 0>
 struct Conv16Cfg {
     static constexpr int KS = KS_, STRIDE = STRIDE_, LOGTW = LOGTW_, MT = MT_, PF = PF_, ABL = ABL_, SPLIT = SPLIT_;
@@ -221,6 +222,14 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
     if (p.nchunks > 1 && !(C::ABL & 2)) issue_loads(1);
     __syncthreads();
+    f16x8 a[MT], al[MT];
+    if constexpr (C::ABL & 8) {                 // ablation: operands read once
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            a[t] = *reinterpret_cast<const f16x8*>(&lds_all[a_base + t * C::RPM * C::STRIDE * RSH]);
+            al[t] = *reinterpret_cast<const f16x8*>(&lds_all[a_base + t * C::RPM * C::STRIDE * RSH + 16]);
+        }
+    }
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const _Float16* lds = lds_all + (chunk & 1) * C::LDS_HALVES;
         _Float16* nxt = lds_all + ((chunk + 1) & 1) * C::LDS_HALVES;
@@ -245,12 +254,13 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
                 int ab = a_base;
                 asm volatile("" : "+v"(ab));                 // no cross-tap CSE of LDS reads (see conv_kernel.h)
                 __builtin_assume((ab & 7) == 0);
-                f16x8 a[MT], al[MT];
+                if constexpr (!(C::ABL & 8)) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    a[t] = *reinterpret_cast<const f16x8*>(&lds[ab + (t * C::RPM * C::STRIDE + ky) * RSH + kx * PSH + j * 16]);
-                    if constexpr (C::SPLIT)
-                        al[t] = *reinterpret_cast<const f16x8*>(&lds[ab + (t * C::RPM * C::STRIDE + ky) * RSH + kx * PSH + KC + j * 16]);
+                    for (int t = 0; t < MT; ++t) {
+                        a[t] = *reinterpret_cast<const f16x8*>(&lds[ab + (t * C::RPM * C::STRIDE + ky) * RSH + kx * PSH + j * 16]);
+                        if constexpr (C::SPLIT)
+                            al[t] = *reinterpret_cast<const f16x8*>(&lds[ab + (t * C::RPM * C::STRIDE + ky) * RSH + kx * PSH + KC + j * 16]);
+                    }
                 }
                 const f16x8 bq = ring[g % PF][0];
                 f16x8 bl;
