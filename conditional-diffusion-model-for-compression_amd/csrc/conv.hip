@@ -144,7 +144,7 @@ Tile select_tile(const cdx_conv_args* a) {
     // Layers at >= 32 pixels wide: the float32 product on the FP16 matrix pipe with split operands (3 MFMAs of 32 cycles
     // per 16 channels against 8 x 64 for the f32-input MFMA): same float32-level error, 2.4x less matrix-pipe time than
     // even the Winograd kernel.  Needs the wpacked_split image; otherwise the float32-MFMA kernels below are used.
-    if (conv_split_ok(a)) return tile_of(WCFG_SPLIT);
+    if (conv_split_ok(a)) return Tile{WCFG_SPLIT, a->stride == 2 ? 64 : 128, 128, 1};
     if (a->ksize == 3) {
         if (hw <= kSplitKMaxPixels) t = tile_of(a->stride == 1 && hw >= 256 ? WCFG_S64 : WCFG_S32);
         else if (cin8_ok(a)) t = tile_of(WCFG_CIN8);
@@ -155,8 +155,8 @@ Tile select_tile(const cdx_conv_args* a) {
 }
 
 bool tile_allowed(const cdx_conv_args* a, int wcfg) {
-    if (a->stride == 2) return wcfg == WCFG_1x4x2 || wcfg == WCFG_2x2x1 || wcfg == WCFG_S32;
     if (wcfg == WCFG_SPLIT) return conv_split_ok(a);
+    if (a->stride == 2) return wcfg == WCFG_1x4x2 || wcfg == WCFG_2x2x1 || wcfg == WCFG_S32;
     if (a->ksize == 1) return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1 || ((wcfg == WCFG_S32 || wcfg == WCFG_S64) && a->wout < 32);
     if (wcfg == WCFG_WINO) return wino_ok(a);
     if (wcfg == WCFG_CIN8) return cin8_ok(a);

@@ -188,7 +188,8 @@ namespace cdx {
 // Is this cdx_conv_f32 launch one the SPLIT kernel is built for?  (conv.hip asks before choosing the tile.)
 bool conv_split_ok(const cdx_conv_args* a) {
     if (!a->wpacked_split || !aligned16(a->wpacked_split) || !(a->wsplit_unscale > 0.f)) return false;
-    if (a->stride != 1 || a->wout < 32 || a->cout <= 4) return false;
+    if (a->wout < 16 || a->cout <= 4) return false;                                   // (8^2 and below: f32-MFMA split-K tiles)
+    if (a->stride == 2 && a->ksize != 3) return false;
     if ((a->out_ld % 4) != 0 || a->out_ld < ((a->cout + 3) & ~3)) return false;      // outputs move as 4-channel vectors
     if ((a->residual || a->stats_out) && (a->cout % 4) != 0) return false;
     return true;
@@ -214,9 +215,18 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift; p.temb = a->temb; p.temb_ld = a->temb_ld;
     p.residual = a->residual;
     p.out = a->out; p.out_f32 = 1; p.out_ld = a->out_ld; p.stats = a->stats_out;
-    p.tiles_x = ceil_div(a->wout, 32);
-    p.tiles_y = ceil_div(a->hout, 4);
+    const int logtw = a->wout >= 32 ? 5 : 4, tw = 1 << logtw, th = (a->stride == 2 ? 64 : 128) / tw;
+    p.tiles_x = ceil_div(a->wout, tw);
+    p.tiles_y = ceil_div(a->hout, th);
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
+    if (a->stride == 2) {      // 64 output pixels x 128 channels, one halo image (DB = 0)
+        if (logtw == 5) return conv16_launch<Conv16Cfg<3, 2, 5, 2, 3, 0, 1, 0>>(p, stream);
+        return conv16_launch<Conv16Cfg<3, 2, 4, 2, 3, 0, 1, 0>>(p, stream);
+    }
+    if (logtw == 4) {
+        if (a->ksize == 3) return conv16_launch<Conv16Cfg<3, 1, 4, 4, 3, 0, 1>>(p, stream);
+        return conv16_launch<Conv16Cfg<1, 1, 4, 4, 3, 0, 1>>(p, stream);
+    }
 #ifdef CDX_TUNING
     if (a->ksize == 3 && variant) {      // timing ablations / tuning variants (tools/conv_bench.py --tiles 60..)
         switch (variant) {

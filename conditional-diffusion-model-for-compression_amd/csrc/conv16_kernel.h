@@ -60,9 +60,11 @@ struct Conv16Params {
 
 // ABL: timing-only ablations (wrong results; libcdx_tune.so only): 1 = no epilogue, 2 = stage only the first chunk,
 // 4 = no weight refills, 8 = no LDS operand reads (registers reused)
-template <int KS_, int STRIDE_, int LOGTW_, int MT_, int PF_ = 3, int ABL_ = 0, int SPLIT_ = 0>
+// DB = 0: ONE halo image and two barriers per chunk (stride-2 SPLIT tiles, whose 5 x 65-pixel hi|lo image would
+// otherwise leave room for a single workgroup per CU).
+template <int KS_, int STRIDE_, int LOGTW_, int MT_, int PF_ = 3, int ABL_ = 0, int SPLIT_ = 0, int DB_ = 1>
 struct Conv16Cfg {
-    static constexpr int KS = KS_, STRIDE = STRIDE_, LOGTW = LOGTW_, MT = MT_, PF = PF_, ABL = ABL_, SPLIT = SPLIT_;
+    static constexpr int KS = KS_, STRIDE = STRIDE_, LOGTW = LOGTW_, MT = MT_, PF = PF_, ABL = ABL_, SPLIT = SPLIT_, DB = DB_;
     static constexpr int PLANES = SPLIT ? 2 : 1;                   // hi | lo
     static constexpr int KC = 32, PSH = KC * PLANES + 8;           // pixel stride in halves (80 B / 144 B)
     static constexpr int TAPS = KS * KS, PAD = KS / 2;
@@ -77,7 +79,7 @@ struct Conv16Cfg {
     static constexpr int NPASS = (NPIX + 63) / 64;                 // 64 pixel slots x 4 channel octets per pass
     static constexpr int GPC = TAPS * 2;                           // (tap, 16-channel step) groups per chunk
     static_assert(TW <= 32 && BM % TW == 0, "tile shape");
-    static_assert(LDS_HALVES * 2 <= 160 * 1024, "LDS budget");
+    static_assert(LDS_HALVES * 2 * (DB ? 2 : 1) <= 160 * 1024, "LDS budget");
     static_assert(GPC % PF == 0 || PF > GPC, "ring depth");
 };
 
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     // two halo images: chunk c+1 is staged into the other one WHILE chunk c's MFMAs run (one pass per MFMA group), one
     // barrier per chunk -- the f16 MFMA leaves the vector ALU free (unlike the f32 one), so the GroupNorm / SiLU /
     // fp16-rounding work of the staging hides under it instead of standing between two barriers.
-    __shared__ __attribute__((aligned(16))) _Float16 lds_all[2 * C::LDS_HALVES];
+    __shared__ __attribute__((aligned(16))) _Float16 lds_all[(C::DB ? 2 : 1) * C::LDS_HALVES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -231,10 +233,10 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
         }
     }
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        const _Float16* lds = lds_all + (chunk & 1) * C::LDS_HALVES;
-        _Float16* nxt = lds_all + ((chunk + 1) & 1) * C::LDS_HALVES;
+        const _Float16* lds = lds_all + (C::DB ? (chunk & 1) * C::LDS_HALVES : 0);
+        _Float16* nxt = lds_all + (C::DB ? ((chunk + 1) & 1) * C::LDS_HALVES : 0);
         const bool more = chunk + 1 < p.nchunks && !(C::ABL & 2);
-        if (!nvalid || GPC <= 2) {
+        if (C::DB && (!nvalid || GPC <= 2)) {
             // a wave without output channels (or a 1x1 layer: two groups per chunk) stages in one go
             if (more) {
 #pragma unroll
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
             const _Float16* __restrict__ wc = wp + (size_t)chunk * (TAPS * 2 * GH);
 #pragma unroll
             for (int g = 0; g < GPC; ++g) {
-                if (GPC > 2 && more) {
+                if (C::DB && GPC > 2 && more) {
                     if (g >= G0 && g < G0 + NPASS) write_pass(nxt, g - G0);
                     if (g == G0 + NPASS && chunk + 2 < p.nchunks) issue_loads(chunk + 2);
                 }
@@ -281,6 +283,14 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
             }
         }
         __syncthreads();
+        if constexpr (!C::DB) {      // single image: every wave is done reading it; write the next chunk in place
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < NPASS; ++i) write_pass(nxt, i);
+                if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
+            }
+            __syncthreads();
+        }
     }
 
     // ---- epilogue ----

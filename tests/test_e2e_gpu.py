@@ -43,14 +43,20 @@ def test_native_library_is_the_path(cdx_mod):
     assert "libcdx.so" in open("/proc/self/maps").read()
 
 
-@pytest.mark.parametrize("name,over", [
-    ("tiny", TINY),
-    ("cfg1", dict(image_size=32, base_channels=64, channel_mult=(1, 2, 2, 2), attn_resolutions=(16,))),
-    ("mid3", dict(image_size=64, base_channels=32, channel_mult=(1, 2, 4), attn_resolutions=(16,), head_dim=64)),
-    # >= 96 channels at >= 32 pixels wide: the 3x3 layers of levels 0 and 1 run as Winograd F(2x2,3x3)
-    ("wide_winograd", dict(image_size=64, base_channels=128, channel_mult=(1, 2, 2), attn_resolutions=(16,), num_res_blocks=1)),
+WIDE = dict(image_size=64, base_channels=128, channel_mult=(1, 2, 2), attn_resolutions=(16,), num_res_blocks=1)
+
+
+@pytest.mark.parametrize("name,over,split", [
+    ("tiny", TINY, True),
+    ("cfg1", dict(image_size=32, base_channels=64, channel_mult=(1, 2, 2, 2), attn_resolutions=(16,)), True),
+    ("cfg1_f32mfma", dict(image_size=32, base_channels=64, channel_mult=(1, 2, 2, 2), attn_resolutions=(16,)), False),
+    ("mid3", dict(image_size=64, base_channels=32, channel_mult=(1, 2, 4), attn_resolutions=(16,), head_dim=64), True),
+    # layers >= 16 pixels wide run on the fp16 matrix pipe with hi|lo split operands (CDX_TILE_SPLIT) ...
+    ("wide_split", WIDE, True),
+    # ... or, without the split weight image, on the f32-input MFMA: >= 96 channels at >= 32 pixels wide as Winograd F(2x2,3x3)
+    ("wide_winograd", WIDE, False),
 ])
-def test_unet_forward_matches_oracle(cdx_mod, record, name, over):
+def test_unet_forward_matches_oracle(cdx_mod, record, name, over, split):
     import oracle
     cfg = cdx_mod.unet_config(**over)
     params = cdx_mod.init_params(cfg, seed=2, affine_jitter=0.1, out_gain=1.0)
@@ -61,7 +67,7 @@ def test_unet_forward_matches_oracle(cdx_mod, record, name, over):
                                    .reshape(3, cfg["image_size"], cfg["image_size"]) for i in range(B)]))
     t = torch.tensor([980, 37])
     want = oracle.unet_forward_ref(cfg, params, x, t, cond, dtype=torch.float64)
-    net = cdx_mod.UNet(cfg, params)
+    net = cdx_mod.UNet(cfg, params, split=split)
     got = net.forward(x.cuda(), t.cuda(), cond.cuda()).cpu()
     err = (got.double() - want).abs().max().item()
     cpu32 = oracle.unet_forward_ref(cfg, params, x, t, cond)
@@ -121,27 +127,40 @@ def test_fused_and_standalone_groupnorm_paths_agree(cdx_mod):
     assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())
 
 
-def test_sampler_winograd_path_vs_live_oracle(cdx_mod, record):
-    """A net wide enough that most 3x3 layers take the Winograd kernels (checked), 10 DDIM steps, against the oracle
-    run on this box's CPU: both PSNR gates."""
+@pytest.mark.parametrize("split,tile", [(True, 11), (False, 7)])
+def test_sampler_split_and_winograd_paths_vs_live_oracle(cdx_mod, record, split, tile):
+    """A net wide enough that most 3x3 layers take the split-fp16 tile (default) or, without the split weight image, the
+    Winograd kernel (checked), 10 DDIM steps, against the oracle run on this box's CPU: both PSNR gates."""
     import ctypes
     import oracle
     cfg = cdx_mod.unet_config(image_size=64, base_channels=128, channel_mult=(1, 2), attn_resolutions=(32,), num_res_blocks=1)
     params = cdx_mod.init_params(cfg, seed=12)
     sb = cdx_mod.synthetic_batch(cfg, 12, 0, 2)
     cond, tgt = torch.from_numpy(sb["cond"]), torch.from_numpy(sb["target"])
-    net = cdx_mod.UNet(cfg, params)
+    net = cdx_mod.UNet(cfg, params, split=split)
     tiles = [cdx_mod._abi.lib().cdx_conv_select_tile(ctypes.byref(a)) for fn, a, _, _ in net.plan(2).calls
              if fn.__name__ == "cdx_conv_f32" and a.ksize == 3]
-    assert tiles.count(7) >= len(tiles) // 2, tiles
+    assert tiles.count(tile) >= len(tiles) // 2, tiles
     got = cdx_mod.Sampler(net).sample(cond.cuda(), 10, seed=12).cpu()
     want = oracle.sample_ref(cfg, params, cond, 10, seed=12)
-    record("sampler_winograd_live", psnr_hip_vs_oracle=psnr(got, want), dpsnr=abs(psnr(got, tgt) - psnr(want, tgt)),
-           winograd_layers=tiles.count(7), conv3x3_layers=len(tiles))
+    record("sampler_split_live" if split else "sampler_winograd_live", psnr_hip_vs_oracle=psnr(got, want),
+           dpsnr=abs(psnr(got, tgt) - psnr(want, tgt)), layers_on_tile=tiles.count(tile), conv3x3_layers=len(tiles))
     assert psnr(got, want) >= 80.0 and abs(psnr(got, tgt) - psnr(want, tgt)) <= 0.01
 
 
-def test_benchmark_config_full_size_vs_live_oracle(cdx_mod, record):
+_CFG2_ORACLE = {}
+
+
+def _cfg2_oracle(cfg, params, cond):
+    """The CPU oracle's 3-step decode of the cfg2 image (~5 s), computed once for both parametrisations."""
+    import oracle
+    if "x" not in _CFG2_ORACLE:
+        _CFG2_ORACLE["x"] = oracle.sample_ref(cfg, params, cond, 3, seed=0)
+    return _CFG2_ORACLE["x"]
+
+
+@pytest.mark.parametrize("split", [True, False])
+def test_benchmark_config_full_size_vs_live_oracle(cdx_mod, record, split):
     """BASELINE.json configs[1] itself -- 256x256, the 113.7 M-parameter 128-ch UNet with bench.py's weights (seed 0) -- one
     image, 3 DDIM steps, against the oracle run on this box's CPU (~1 s per step): both PSNR gates at the size the
     headline number is measured on, through every kernel / tile kind that bench.py times."""
@@ -150,9 +169,9 @@ def test_benchmark_config_full_size_vs_live_oracle(cdx_mod, record):
     params = cdx_mod.init_params(cfg, seed=0)
     sb = cdx_mod.synthetic_batch(cfg, 0, 0, 1)
     cond, tgt = torch.from_numpy(sb["cond"]), torch.from_numpy(sb["target"])
-    got = cdx_mod.Sampler(cdx_mod.UNet(cfg, params)).sample(cond.cuda(), 3, seed=0).cpu()
-    want = oracle.sample_ref(cfg, params, cond, 3, seed=0)
-    record("sampler_cfg2_full_size", psnr_hip_vs_oracle=psnr(got, want), dpsnr=abs(psnr(got, tgt) - psnr(want, tgt)),
+    got = cdx_mod.Sampler(cdx_mod.UNet(cfg, params, split=split)).sample(cond.cuda(), 3, seed=0).cpu()
+    want = _cfg2_oracle(cfg, params, cond)
+    record("sampler_cfg2_full_size" + ("" if split else "_f32mfma"), psnr_hip_vs_oracle=psnr(got, want), dpsnr=abs(psnr(got, tgt) - psnr(want, tgt)),
            max_err=(got - want).abs().max().item())
     assert psnr(got, want) >= 80.0 and abs(psnr(got, tgt) - psnr(want, tgt)) <= 0.01
 

@@ -67,10 +67,10 @@ def tiles_for(k, s, wout=0, cout=999, cin=999):
     """Every tile shape built for this ksize / stride (include/cdx.h CDX_TILE_*), plus -1 = the library's pick.
     Tile 7 = Winograd F(2x2,3x3) (3x3 stride 1, output width >= 32)."""
     if k == 1:
-        return (-1, 0, 1, 2) + ((5, 6) if wout < 32 else ()) + ((11,) if wout >= 32 and cout > 4 else ())
+        return (-1, 0, 1, 2) + ((5, 6) if wout < 32 else ()) + ((11,) if wout >= 16 and cout > 4 else ())
     if s == 2:
-        return (-1, 3, 4, 5)
-    return (-1, 0, 1, 2, 5, 6) + ((8, 9) if wout >= 32 and cout <= 4 else ()) + ((10,) if wout >= 32 and cin <= 8 and cout > 4 else ()) + ((7,) if wout >= 32 else ()) + ((11,) if wout >= 32 and cout > 4 else ())     # 7 = Winograd F(2x2,3x3); 11 = split-fp16 operands on the fp16 matrix pipe
+        return (-1, 3, 4, 5) + ((11,) if wout >= 16 and cout > 4 else ())
+    return (-1, 0, 1, 2, 5, 6) + ((8, 9) if wout >= 32 and cout <= 4 else ()) + ((10,) if wout >= 32 and cin <= 8 and cout > 4 else ()) + ((7,) if wout >= 32 else ()) + ((11,) if wout >= 16 and cout > 4 else ())     # 7 = Winograd F(2x2,3x3); 11 = split-fp16 operands on the fp16 matrix pipe
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
@@ -128,7 +128,8 @@ def test_conv_fused_gn_silu_concat_temb_residual(cdx_mod, B, c0, c1, co, H, W, g
                                                         (2, 32, 64, 0, 40, 24, 3, 2, -1), (3, 32, 32, 32, 4, 4, 3, 1, -1), (1, 32, 160, 0, 64, 64, 3, 1, -1),
                                                         (2, 32, 160, 128, 40, 72, 3, 1, -1), (3, 64, 128, 0, 8, 32, 3, 1, -1),     # Winograd kernel, ragged tiles
                                                         (1, 32, 4, 0, 34, 42, 3, 1, -1)])       # cout = 4 WITH sums: not the small kernels (found by tools/fuzz_conv.py)
-def test_conv_epilogue_stats_match_standalone_gn(cdx_mod, B, ci, c_a, c_b, H, W, k, s, tile):
+@pytest.mark.parametrize("split", [True, False], ids=["split", "f32mfma"])
+def test_conv_epilogue_stats_match_standalone_gn(cdx_mod, B, ci, c_a, c_b, H, W, k, s, tile, split):
     """GroupNorm statistics accumulated in the producing convs' epilogues (one or two producers = concat) give the
     same scale/shift as the standalone pass over the stored tensors, and as float64 torch."""
     ops = cdx_mod.ops
@@ -136,7 +137,7 @@ def test_conv_epilogue_stats_match_standalone_gn(cdx_mod, B, ci, c_a, c_b, H, W,
     outs, stats = [], []
     for j, co in enumerate([c for c in (c_a, c_b) if c]):
         w = rnd(co, ci, k, k, seed=61 + j, scale=1.0 / math.sqrt(ci * k * k))
-        pc = ops.PackedConv(w.numpy(), rnd(co, seed=63 + j).numpy() + 3.0, ci)      # biased: non-zero mean
+        pc = ops.PackedConv(w.numpy(), rnd(co, seed=63 + j).numpy() + 3.0, ci, split=split)      # biased: non-zero mean
         o, st = ops.conv(pc, x, stride=s, want_stats=True, tile=tile)
         outs.append(o)
         stats.append(st)
