@@ -219,9 +219,10 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
     int rc = validate(a);
     if (rc) return rc;
 #ifdef CDX_TUNING
-    if (tile >= 60) {                       // split-tile ablations / variants (conv16.hip)
+    if (tile >= 60) {                       // split-tile ablations / variants (conv16.hip); same slot geometry as tile 11
         int rc60 = validate(a);
         if (rc60) return rc60;
+        if (a->stats_out && select_tile(a).wcfg != WCFG_SPLIT) return CDX_EINVAL;
         return conv_split_ok(a) ? conv_split_launch(a, static_cast<hipStream_t>(stream), tile - 60) : CDX_ENOTSUP;
     }
     const bool experimental = tile >= 16;   // conv_exp.hip (16..30) / conv_wino.hip (31..): timing ablations (libcdx_tune.so)
@@ -247,7 +248,7 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
     p.w = a->wpacked; p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift;
     p.temb = a->temb; p.temb_ld = a->temb_ld; p.residual = a->residual; p.out = a->out; p.out_ld = a->out_ld;
     p.stats = a->stats_out;
-    if (a->stats_out && tile >= 0) return CDX_EINVAL;   // slot count is defined for the library's own tile choice
+    if (a->stats_out && tile >= 0 && tile != select_tile(a).wcfg) return CDX_EINVAL;   // slot count is defined for the library's own tile choice
 
     const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : a->wout >= 8 ? 3 : 2;
     const int tw = 1 << logtw, th = t.bm / tw;

@@ -188,7 +188,8 @@ namespace cdx {
 // Is this cdx_conv_f32 launch one the SPLIT kernel is built for?  (conv.hip asks before choosing the tile.)
 bool conv_split_ok(const cdx_conv_args* a) {
     if (!a->wpacked_split || !aligned16(a->wpacked_split) || !(a->wsplit_unscale > 0.f)) return false;
-    if (a->wout < 16 || a->cout <= 4) return false;                                   // (8^2 and below: f32-MFMA split-K tiles)
+    if (a->wout < 16 || a->cout <= 4) return false;
+    if ((a->c0 % 8) != 0 || (a->c1 % 8) != 0) return false;                           // the loader moves 8-channel octets                                   // (8^2 and below: f32-MFMA split-K tiles)
     if (a->stride == 2 && a->ksize != 3) return false;
     if ((a->out_ld % 4) != 0 || a->out_ld < ((a->cout + 3) & ~3)) return false;      // outputs move as 4-channel vectors
     if ((a->residual || a->stats_out) && (a->cout % 4) != 0) return false;
@@ -237,6 +238,11 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
             case 7: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 7, 1>>(p, stream);
             case 8: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 8, 1>>(p, stream);      // no LDS operand reads
             case 15: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 15, 1>>(p, stream);    // MFMA stream only
+            case 20: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 16, 1>>(p, stream);    // no residual loads
+            case 21: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 32, 1>>(p, stream);    // no GroupNorm sums
+            case 22: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 48, 1>>(p, stream);    // neither
+            case 23: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 64, 1>>(p, stream);    // halo loads of chunks 0, 1 only
+            case 24: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 68, 1>>(p, stream);    // + no weight refills
             case 16: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 6, 0, 1>>(p, stream);     // ring depth 6
             case 17: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 2, 0, 1>>(p, stream);     // ring depth 2
             default: return CDX_ENOTSUP;

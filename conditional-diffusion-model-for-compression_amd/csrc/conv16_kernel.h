@@ -59,7 +59,8 @@ struct Conv16Params {
 };
 
 // ABL: timing-only ablations (wrong results; libcdx_tune.so only): 1 = no epilogue, 2 = stage only the first chunk,
-// 4 = no weight refills, 8 = no LDS operand reads (registers reused)
+// 4 = no weight refills, 8 = no LDS operand reads (registers reused), 16 = no residual loads, 32 = no GroupNorm sums,
+// 64 = halo global loads only for chunks 0 and 1 (later chunks restage stale registers: VALU + LDS-write cost stays)
 // DB = 0: ONE halo image and two barriers per chunk (stride-2 SPLIT tiles, whose 5 x 65-pixel hi|lo image would
 // otherwise leave room for a single workgroup per CU).
 template <int KS_, int STRIDE_, int LOGTW_, int MT_, int PF_ = 3, int ABL_ = 0, int SPLIT_ = 0, int DB_ = 1>
@@ -87,8 +88,11 @@ __device__ __forceinline__ float silu16_f(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
 }
 
-template <class C>
+// STG (compile-time staging mode, chosen at launch from the GN / SiLU flags -- a runtime flag costs a v_cndmask per element
+// and flag in the staging code): 0 = plain, 1 = GroupNorm scale/shift, 2 = GroupNorm + SiLU, 3 = SiLU only.
+template <class C, int STG>
 __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
+    constexpr bool kGN = STG == 1 || STG == 2, kSILU = STG == 2 || STG == 3;
     constexpr int KC = C::KC, PSH = C::PSH, RSH = C::RSH, TAPS = C::TAPS, MT = C::MT, NPASS = C::NPASS, GPC = C::GPC;
     constexpr int PF = C::PF < GPC ? C::PF : GPC;
     // two halo images: chunk c+1 is staged into the other one WHILE chunk c's MFMAs run (one pass per MFMA group), one
@@ -126,20 +130,38 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     f32x4 gsc[2], gsh[2];
     bool cvalid;
 
+    // Halo loads use buffer addressing: per-lane byte offset voff[i] = (pixel * channels + 8 q) * elem (one 32-bit VGPR per
+    // pass, recomputed only when the chunk sequence moves from src0 to src1), scalar offset = chunk * 32 channels * elem.
+    // hipcc's flat form spent ~25 VALU instructions of 64-bit address arithmetic per load (a 200-instruction clump per chunk).
+    // The resource is bounded to the tensor: a lane whose channel octet lies past the source's end (zero-filled at write
+    // time) may read past the last pixel -- such reads return 0 instead of faulting.
+    unsigned voff[NPASS];
+    __amdgpu_buffer_rsrc_t srs;
+    int cur_src = -1;
+    const unsigned esz = (C::SPLIT || p.src_f32) ? 4u : 2u;
+    auto bind_source = [&](int sidx) {
+        const unsigned cs = (unsigned)p.csrc[sidx];
+        const size_t bytes = (size_t)p.B * p.Hin * p.Win * cs * esz;
+        srs = buf_rsrc(p.src[sidx], bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes);
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) voff[i] = ((unsigned)soff[i] * cs + 8u * (unsigned)q) * esz;
+        cur_src = sidx;
+    };
     auto issue_loads = [&](int chunk) {
         const int s = chunk >= p.nchunk0;
-        const int cl = (s ? chunk - p.nchunk0 : chunk) * KC + q * 8;
+        if (s != cur_src) bind_source(s);            // wave-uniform, at most twice per tile
+        const int cc = s ? chunk - p.nchunk0 : chunk;
+        const int cl = cc * KC + q * 8;
         const int cs = p.csrc[s];
         cvalid = cl < cs;                       // channel counts are multiples of 8 (fp16) / 4 (fp32 conv_in: see host)
-        const int c0 = cvalid ? cl : 0;
-        if (p.src_f32) {
-            const float* __restrict__ base = static_cast<const float*>(p.src[s]) + c0;
-            const bool hi = c0 + 8 <= cs;       // fp32 sources may end on a 4-channel boundary
+        const unsigned so = (unsigned)cc * (unsigned)KC * esz;
+        if (C::SPLIT || p.src_f32) {
+            // fp32 sources of the fp16-storage path may end on a 4-channel boundary (SPLIT: multiples of 8, see conv_split_ok)
+            const bool hi = C::SPLIT || cl + 8 <= cs;
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) {
-                const float* a = base + (size_t)soff[i] * cs;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(a);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(hi ? a + 4 : a);
+                const f32x4 v0 = buf_load4(srs, voff[i], so);
+                const f32x4 v1 = buf_load4(srs, voff[i] + 16u, so);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     pre[i][e] = v0[e];
@@ -147,15 +169,14 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
                 }
             }
         } else {
-            const _Float16* __restrict__ base = static_cast<const _Float16*>(p.src[s]) + c0;
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) {
-                const f16x8 v = *reinterpret_cast<const f16x8*>(base + (size_t)soff[i] * cs);
+                const f16x8 v = __builtin_bit_cast(f16x8, buf_load4(srs, voff[i], so));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pre[i][e] = (float)v[e];
             }
         }
-        if (p.gn) {
+        if constexpr (kGN) {
             const int cg = cvalid ? (s ? p.csrc[0] : 0) + cl : 0;
             const float* gs = p.gscale + (size_t)b * p.ctot + cg;
             const float* gh = p.gshift + (size_t)b * p.ctot + cg;
@@ -166,28 +187,43 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
         }
     };
 
-    auto write_pass = [&](_Float16* lds, int i) {
-        {
-            const int hp = i * 64 + pl;
-            const int hy = hp / C::HW, hx = hp - hy * C::HW;
-            const bool ok = cvalid && ((vmask >> i) & 1u);
-            f16x8 o, ol;
+    // Staging is cut into UNITS of half a pass (one pixel slot x 4 channels per thread: ~45 VALU instructions), so that a
+    // unit rides on ONE 12-MFMA group without exceeding the issue slots the fp16 MFMA leaves free (a whole pass between two
+    // MFMAs was a 128-instruction clump behind an exec-mask branch).  unit u = (pass u >> 1, channel half u & 1).
+    using f16x4s = __attribute__((ext_vector_type(4))) _Float16;
+    f16x4s uo, uol;                                   // the unit being computed (hi | lo)
+    auto unit_elem = [&](int u, int k) {              // channel k of unit u
+        const int i = u >> 1, h = u & 1;
+        const bool ok = cvalid && ((vmask >> i) & 1u);
+        float v = pre[i][4 * h + k];
+        if constexpr (kGN) v = fmaf(v, gsc[h][k], gsh[h][k]);
+        if constexpr (kSILU) v = silu16_f(v);
+        if constexpr (C::SPLIT) {
+            v = ok ? __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f) : 0.f;      // saturate instead of inf
+            uo[k] = (_Float16)v;
+            uol[k] = (_Float16)(v - (float)uo[k]);                             // exact difference, rounded once
+        } else uo[k] = (_Float16)(ok ? v : 0.f);
+    };
+    auto unit_store = [&](_Float16* lds, int u) {
+        const int i = u >> 1, h = u & 1;
+        const int hp = i * 64 + pl;
+        const int hy = hp / C::HW, hx = hp - hy * C::HW;
+        // slots past the halo's last pixel (last pass only) dump into the 16 unused pad bytes of the thread's pass-0 pixel:
+        // an unconditional store keeps the unit free of exec-mask branches (which pin its VALU work in one clump)
+        const int off = ((i + 1) * 64 <= C::NPIX || hp < C::NPIX) ? hy * RSH + hx * PSH + q * 8 + 4 * h
+                                                                   : (pl / C::HW) * RSH + (pl % C::HW) * PSH + KC * C::PLANES;
+        const int off_lo = ((i + 1) * 64 <= C::NPIX || hp < C::NPIX) ? off + KC : off + 4;
+        *reinterpret_cast<f16x4s*>(&lds[off]) = uo;
+        if constexpr (C::SPLIT) *reinterpret_cast<f16x4s*>(&lds[off_lo]) = uol;
+    };
+    auto write_unit = [&](_Float16* lds, int u) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float v = pre[i][e];
-                if (p.gn) v = fmaf(v, gsc[e >> 2][e & 3], gsh[e >> 2][e & 3]);
-                if (p.silu) v = silu16_f(v);
-                if constexpr (C::SPLIT) {
-                    v = ok ? __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f) : 0.f;      // saturate instead of inf
-                    o[e] = (_Float16)v;
-                    ol[e] = (_Float16)(v - (float)o[e]);                               // exact difference, rounded once
-                } else o[e] = (_Float16)(ok ? v : 0.f);
-            }
-            if (hp < C::NPIX) {
-                *reinterpret_cast<f16x8*>(&lds[hy * RSH + hx * PSH + q * 8]) = o;
-                if constexpr (C::SPLIT) *reinterpret_cast<f16x8*>(&lds[hy * RSH + hx * PSH + KC + q * 8]) = ol;
-            }
-        }
+        for (int k = 0; k < 4; ++k) unit_elem(u, k);
+        unit_store(lds, u);
+    };
+    auto write_pass = [&](_Float16* lds, int i) {
+        write_unit(lds, 2 * i);
+        write_unit(lds, 2 * i + 1);
     };
 
     // ---- MFMA operand addressing ----
@@ -204,6 +240,44 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // SPLIT: bias + temb + residual enter through the accumulator init (scaled by 1/unscale, a power of two: exact), so the
+    // residual tile is fetched under the first chunk's staging instead of standing between the last MFMA and the stores
+    // (measured: the epilogue's residual loads were 6 % of the kernel).  Accumulator layout of the 32x32 MFMA: lane = channel
+    // n, register r of tile t = pixel m = 32 t + 8 (r >> 2) + 4 (lane >> 5) + (r & 3): one dword per lane, 128 B per half wave.
+    if constexpr (C::SPLIT) {
+        static_assert(C::LOGTW >= 3, "accumulator-init addressing assumes 8-pixel runs inside a tile row");
+        const int n = ntile * 32 + li;
+        if (nvalid && n < p.Cout) {
+            const float inv = 1.0f / p.wunscale;
+            float add = p.bias ? p.bias[n] : 0.f;
+            if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
+            add *= inv;
+            if (p.residual && !(C::ABL & 16)) {
+                // rows past the image end / columns past the row end read other (or no: bounded resource) pixels; those
+                // accumulators are never stored
+                const size_t first = (((size_t)b * p.Hout + oy0) * p.Wout + ox0) * p.Cout;
+                const size_t left = ((size_t)p.B * p.Hout * p.Wout * p.Cout - first) * 4;
+                const __amdgpu_buffer_rsrc_t rr = buf_rsrc(static_cast<const float*>(p.residual) + first,
+                                                           left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)left);
+                const unsigned voff = ((unsigned)(4 * lh) * (unsigned)p.Cout + (unsigned)n) * 4u;
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        constexpr int dummy = 0;
+                        const int mb = t * 32 + 8 * (r >> 2) + (r & 3);
+                        const unsigned pix = (unsigned)(mb >> C::LOGTW) * (unsigned)p.Wout + (unsigned)(mb & (C::TW - 1));
+                        acc[t][r] = fmaf(buf_load1(rr, voff, pix * (unsigned)p.Cout * 4u), inv, add);
+                        (void)dummy;
+                    }
+            } else {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = add;
+            }
+        }
+    }
 
     f16x8 ring[PF][C::PLANES];
 #pragma unroll
@@ -217,8 +291,9 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     const int cq = ntile * 32 + (li & ~3);                    // first of this quad's 4 channels
     const bool quad_ok = nvalid && cq < p.Cout;               // (cout is a multiple of 4 or the tail is zero-weighted)
     // staging schedule inside a chunk: passes at groups G0 .. G0+NPASS-1, the loads of the chunk after next right behind
-    constexpr int G0 = GPC > NPASS + 1 ? GPC - NPASS - 1 : 0;
-    static_assert(NPASS + 1 <= GPC || GPC <= 2, "staging passes must fit in the chunk's groups (1x1: done after the groups)");
+    constexpr int NU = 2 * NPASS;
+    constexpr int G0 = GPC > NU + 1 ? GPC - NU - 1 : 0;
+    static_assert(NU + 1 <= GPC || GPC <= 2 || !C::DB, "staging units must fit in the chunk's groups (1x1: done after the groups)");
     issue_loads(0);
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
@@ -248,10 +323,17 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
             const _Float16* __restrict__ wc = wp + (size_t)chunk * (TAPS * 2 * GH);
 #pragma unroll
             for (int g = 0; g < GPC; ++g) {
-                if (C::DB && GPC > 2 && more) {
-                    if (g >= G0 && g < G0 + NPASS) write_pass(nxt, g - G0);
-                    if (g == G0 + NPASS && chunk + 2 < p.nchunks) issue_loads(chunk + 2);
-                }
+                // Staging groups (g in [G0, G0 + NU), next chunk exists): the unit's four channel computations are placed
+                // BETWEEN quarters of the group's MFMAs, fenced by sched_barriers -- left alone the scheduler emits the unit's
+                // ~60 VALU instructions as one clump in front of the group's first MFMA (and sched_group_barrier pipelines
+                // did not move them).  A quarter = 3 MFMAs (96 matrix-pipe cycles) + ~14 VALU instructions.
+                constexpr int NM = MT * (C::SPLIT ? 3 : 1);                  // MFMAs per group
+                constexpr bool kInterleave = C::DB && GPC > 2 && (NM % 4) == 0 && !(C::ABL & 128);
+                // (compile-time: in the LAST chunk the unit restages stale registers into the idle image -- harmless, and it
+                // keeps the unrolled chunk body free of runtime branches, which would cut it into small scheduling regions)
+                const bool stage_here = C::DB && GPC > 2 && !(C::ABL & 2) && g >= G0 && g < G0 + NU;
+                if (stage_here && !kInterleave) write_unit(nxt, g - G0);
+                if (C::DB && GPC > 2 && more && g == G0 + NU && chunk + 2 < p.nchunks && !(C::ABL & 64)) issue_loads(chunk + 2);
                 const int tap = g >> 1, j = g & 1, ky = tap / C::KS, kx = tap % C::KS;
                 int ab = a_base;
                 asm volatile("" : "+v"(ab));                 // no cross-tap CSE of LDS reads (see conv_kernel.h)
@@ -272,13 +354,24 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
                     for (int pl_ = 0; pl_ < C::PLANES; ++pl_)      // wraps into the next chunk / tail pad
                         ring[g % PF][pl_] = *reinterpret_cast<const f16x8*>(wc + (size_t)(g + PF) * GH + pl_ * 512);
                 }
+                // MFMA m of the group: term m / MT (hi*hi, lo*hi, hi*lo; lo*lo <= 2^-22 of the product is dropped), tile m % MT
+                auto mfma_at = [&](int m) {
+                    const int t = m % MT, term = m / MT;
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 1 ? al[t] : a[t], term == 2 ? bl : bq, acc[t], 0, 0, 0);
+                };
+                if (kInterleave && stage_here) {
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t], bq, acc[t], 0, 0, 0);
-                if constexpr (C::SPLIT) {      // the two cross terms (lo*lo, <= 2^-22 of the product, is dropped)
+                    for (int k = 0; k < 4; ++k) {
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bq, acc[t], 0, 0, 0);
+                        for (int m = k * (NM / 4); m < (k + 1) * (NM / 4); ++m) mfma_at(m);
+                        unit_elem(g - G0, k);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    unit_store(nxt, g - G0);
+                } else {
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t], bl, acc[t], 0, 0, 0);
+                    for (int m = 0; m < NM; ++m) mfma_at(m);
                 }
             }
         }
@@ -337,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
             for (int k = 0; k < 4; ++k) {
                 float x[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) x[c] = C::SPLIT ? fmaf(acc[t][4 * k + c], un, add) : acc[t][4 * k + c] + add;
+                for (int c = 0; c < 4; ++c) x[c] = C::SPLIT ? acc[t][4 * k + c] * un : acc[t][4 * k + c] + add;
                 quad_transpose(x, q4);                        // now: pixel 8k + q4 (+4 lh) of tile t, channels cq..cq+3
                 const int m = t * 32 + 8 * k + q4 + 4 * lh;
                 const int oy = oy0 + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
@@ -367,12 +460,8 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    if constexpr (C::SPLIT) {          // float32 in, float32 out
-        if (p.residual) {
-            if (p.stats) epilogue(T_{}, T_{}, T_{}); else epilogue(T_{}, F_{}, T_{});
-        } else {
-            if (p.stats) epilogue(F_{}, T_{}, T_{}); else epilogue(F_{}, F_{}, T_{});
-        }
+    if constexpr (C::SPLIT) {          // float32 in, float32 out; bias / temb / residual are already in the accumulators
+        if (p.stats && !(C::ABL & 32)) epilogue(F_{}, T_{}, T_{}); else epilogue(F_{}, F_{}, T_{});
     } else if (p.out_f32) {
         if (p.residual) epilogue(T_{}, F_{}, T_{}); else epilogue(F_{}, F_{}, T_{});
     } else if (p.residual) {
@@ -408,7 +497,12 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
 template <class C>
 inline int conv16_launch(const Conv16Params& p, hipStream_t stream) {
     dim3 grid(p.tiles_x * p.tiles_y * p.B, ceil_div(p.Cout, C::BN));
-    hipLaunchKernelGGL(conv16_kernel<C>, grid, dim3(256), 0, stream, p);
+    switch (p.gn ? (p.silu ? 2 : 1) : (p.silu ? 3 : 0)) {
+        case 0: hipLaunchKernelGGL((conv16_kernel<C, 0>), grid, dim3(256), 0, stream, p); break;
+        case 1: hipLaunchKernelGGL((conv16_kernel<C, 1>), grid, dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((conv16_kernel<C, 2>), grid, dim3(256), 0, stream, p); break;
+        default: hipLaunchKernelGGL((conv16_kernel<C, 3>), grid, dim3(256), 0, stream, p); break;
+    }
     return check_launch();
 }
 

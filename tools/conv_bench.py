@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="16,256,256,128,0,128,3,1")
 ap.add_argument("--tiles", default="-1")
 ap.add_argument("--gn", action="store_true", help="fuse GroupNorm scale/shift + SiLU on load + temb + residual (ResBlock conv)")
+ap.add_argument("--stats", action="store_true", help="also produce the GroupNorm partial sums of the output (as every normed layer of the UNet does)")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 a = ap.parse_args()
@@ -34,6 +35,8 @@ if a.gn:
     kw = dict(gn=ops.gn_stats(x0, x1, gamma, beta, 32), silu=True, temb=torch.randn(B, co, device="cuda"),
               residual=torch.randn(B, ho, wo, co, device="cuda"))
 args = ops.conv_args(pc, x0, x1, out, stride=s, **kw)
+if a.stats:
+    _stats_keep = ops.conv_stats_buffer(args, "cuda")
 flops = 2.0 * B * ho * wo * co * (c0 + c1) * k * k
 tiles = [int(t) for t in a.tiles.split(",")]
 L = _abi.lib()
