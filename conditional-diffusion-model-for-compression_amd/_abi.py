@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcdx_tune.so" if os.environ.get("CDX_TUNE") == "1" else "libcdx.so")
 
 ABI_VERSION = 3
-CONV_UPSAMPLE2X, CONV_GN, CONV_SILU = 1, 2, 4
+CONV_UPSAMPLE2X, CONV_GN, CONV_SILU, CONV_BF16 = 1, 2, 4, 8
 LINEAR_SILU_IN = 1
 CONV_KC = 32
 
@@ -103,6 +103,7 @@ OPS = {
     "gn_stats_f32": GnStatsArgs,
     "gn_finalize_f32": GnFinalizeArgs,
     "attn_f32": AttnArgs,
+    "attn_bf16": AttnArgs,
     "linear_f32": LinearArgs,
     "timestep_embedding_f32": TimestepEmbeddingArgs,
     "diffusion_update_f32": DiffusionUpdateArgs,
@@ -119,7 +120,7 @@ EXPORTS = (["cdx_abi_version", "cdx_strerror", "cdx_launch_count",
             "cdx_conv_packed_floats", "cdx_conv_pack_weights_f32", "cdx_conv_select_tile", "cdx_conv_f32_tile",
             "cdx_conv_stats_slots", "cdx_conv_wino_packed_floats", "cdx_conv_pack_weights_wino_f32",
             "cdx_conv_f16_stats_slots", "cdx_conv_f16_packed_halves", "cdx_conv_pack_weights_f16",
-            "cdx_conv_split_packed_halves", "cdx_conv_pack_weights_split_f16"]
+            "cdx_conv_split_packed_halves", "cdx_conv_pack_weights_split_f16", "cdx_conv_pack_weights_bf16"]
            + [f"cdx_{op}" for op in OPS] + [f"cdx_{op}_workspace" for op in OPS])
 
 _lib = None
@@ -158,6 +159,8 @@ def lib() -> C.CDLL:
     L.cdx_conv_f16_packed_halves.argtypes = [_i, _i, _i, _i]
     L.cdx_conv_pack_weights_f16.restype = C.c_int
     L.cdx_conv_pack_weights_f16.argtypes = [_f, _i, _i, _i, _i, _f]
+    L.cdx_conv_pack_weights_bf16.restype = C.c_int
+    L.cdx_conv_pack_weights_bf16.argtypes = [_f, _i, _i, _i, _i, _f]
     L.cdx_conv_split_packed_halves.restype = C.c_size_t
     L.cdx_conv_split_packed_halves.argtypes = [_i, _i, _i, _i]
     L.cdx_conv_pack_weights_split_f16.restype = C.c_int
@@ -250,3 +253,17 @@ def pack_conv_weights_split(w_oihw, c0: int, c1: int):
     check(lib().cdx_conv_pack_weights_split_f16(w.ctypes.data, c0, c1, cout, k, out.ctypes.data, C.byref(un)),
           "cdx_conv_pack_weights_split_f16")
     return out, float(un.value)
+
+
+def pack_conv_weights_bf16(w_oihw, c0: int, c1: int):
+    """numpy OIHW float32 -> bfloat16 fragment image as numpy uint16 bit patterns (host)."""
+    import numpy as np
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    cout, cin, k, _ = w.shape
+    assert cin == c0 + c1
+    n = int(lib().cdx_conv_f16_packed_halves(c0, c1, cout, k))
+    if n == 0:
+        raise CdxError("cdx_conv_f16_packed_halves: bad arguments")
+    out = np.empty(n, np.uint16)
+    check(lib().cdx_conv_pack_weights_bf16(w.ctypes.data, c0, c1, cout, k, out.ctypes.data), "cdx_conv_pack_weights_bf16")
+    return out

@@ -48,8 +48,8 @@ def validate_unet_config(cfg: dict) -> dict:
     ch, g = cfg["base_channels"], cfg["groups"]
     if cfg["cond_mode"] not in ("concat", "cross_attn"):
         raise ValueError(f"cond_mode must be 'concat' or 'cross_attn', got {cfg['cond_mode']!r}")
-    if cfg["dtype"] not in ("fp32", "fp16"):
-        raise ValueError(f"dtype must be 'fp32' or 'fp16', got {cfg['dtype']!r}")
+    if cfg["dtype"] not in ("fp32", "fp16", "bf16"):
+        raise ValueError(f"dtype must be 'fp32', 'fp16' or 'bf16', got {cfg['dtype']!r}")
     nlev = len(cfg["channel_mult"])
     if cfg["image_size"] % (1 << (nlev - 1)):
         raise ValueError("image_size must be divisible by 2**(levels-1)")

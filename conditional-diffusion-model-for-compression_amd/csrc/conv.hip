@@ -170,7 +170,7 @@ int validate(const cdx_conv_args* a) {
     CDX_REQUIRE((a->c1 == 0) == (a->src1 == nullptr));
     if (a->c1) CDX_REQUIRE((a->c0 % CDX_CONV_KC) == 0 && (a->c1 % CDX_CONV_KC) == 0);
     CDX_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->cout > 0);
-    CDX_REQUIRE((a->flags & ~(CDX_CONV_UPSAMPLE2X | CDX_CONV_GN | CDX_CONV_SILU)) == 0);   // unknown flag bits are an error
+    CDX_REQUIRE((a->flags & ~(CDX_CONV_UPSAMPLE2X | CDX_CONV_GN | CDX_CONV_SILU)) == 0);   // unknown flag bits are an error (CDX_CONV_BF16: cdx_conv_f16 only)
     CDX_REQUIRE(a->ksize == 1 || a->ksize == 3);
     CDX_REQUIRE(a->stride == 1 || (a->stride == 2 && a->ksize == 3));
     const int ups = (a->flags & CDX_CONV_UPSAMPLE2X) ? 1 : 0;

@@ -17,9 +17,9 @@ int validate(const cdx_conv_f16_args* a) {
     if (a->c1) CDX_REQUIRE((a->c0 % 32) == 0 && (a->c1 % 32) == 0);
     CDX_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->cout > 0);
 #ifdef CDX_TUNING
-    CDX_REQUIRE((a->flags & ~(CDX_CONV_UPSAMPLE2X | CDX_CONV_GN | CDX_CONV_SILU | 0x700)) == 0);
+    CDX_REQUIRE((a->flags & ~(CDX_CONV_UPSAMPLE2X | CDX_CONV_GN | CDX_CONV_SILU | CDX_CONV_BF16 | 0x700)) == 0);
 #else
-    CDX_REQUIRE((a->flags & ~(CDX_CONV_UPSAMPLE2X | CDX_CONV_GN | CDX_CONV_SILU)) == 0);   // unknown flag bits are an error
+    CDX_REQUIRE((a->flags & ~(CDX_CONV_UPSAMPLE2X | CDX_CONV_GN | CDX_CONV_SILU | CDX_CONV_BF16)) == 0);   // unknown flag bits are an error
 #endif
     CDX_REQUIRE(a->ksize == 1 || a->ksize == 3);
     CDX_REQUIRE(a->stride == 1 || (a->stride == 2 && a->ksize == 3));
@@ -46,7 +46,7 @@ void tile_grid(const cdx_conv_f16_args* a, int& logtw, int& tx, int& ty) {
 }  // namespace
 
 namespace cdx {
-int conv16_dispatch(int ks, int stride, int logtw, const Conv16Params& p, hipStream_t stream) {
+int conv16_dispatch(int ks, int stride, int logtw, bool bf, const Conv16Params& p, hipStream_t stream) {
 #ifdef CDX_TUNING
     // timing ablations of the dominant shape (libcdx_tune.so only), selected by flag bits 8..10
     if (ks == 3 && stride == 1 && logtw == 5 && p.abl) {
@@ -60,7 +60,9 @@ int conv16_dispatch(int ks, int stride, int logtw, const Conv16Params& p, hipStr
         }
     }
 #endif
-#define C16(KS, ST, LT, MT) if (ks == KS && stride == ST && logtw == LT) return conv16_launch<Conv16Cfg<KS, ST, LT, MT>>(p, stream);
+#define C16(KS, ST, LT, MT)                                                                      \
+    if (ks == KS && stride == ST && logtw == LT)                                                 \
+        return bf ? conv16_launch<Conv16Cfg<KS, ST, LT, MT, 3, 0, 0, 1, 1>>(p, stream) : conv16_launch<Conv16Cfg<KS, ST, LT, MT>>(p, stream);
     C16(3, 1, 2, 4) C16(3, 1, 3, 4) C16(3, 1, 4, 4) C16(3, 1, 5, 4)
     C16(1, 1, 2, 4) C16(1, 1, 3, 4) C16(1, 1, 4, 4) C16(1, 1, 5, 4)
     C16(3, 2, 2, 2) C16(3, 2, 3, 2) C16(3, 2, 4, 2) C16(3, 2, 5, 2)
@@ -97,6 +99,31 @@ extern "C" int cdx_conv_pack_weights_f16(const float* w, int32_t c0, int32_t c1,
     return CDX_OK;
 }
 
+extern "C" int cdx_conv_pack_weights_bf16(const float* w, int32_t c0, int32_t c1, int32_t cout, int32_t ksize, uint16_t* packed) {
+    CDX_REQUIRE(w && packed && c0 > 0 && c1 >= 0 && cout > 0 && (ksize == 1 || ksize == 3));
+    const int taps = ksize * ksize, ctot = c0 + c1;
+    const int nch0 = chunks_of(c0), nch = nch0 + chunks_of(c1), ntiles = (cout + 31) / 32;
+    uint16_t* o = packed;
+    for (int nt = 0; nt < ntiles; ++nt)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int j = 0; j < 2; ++j)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int n = nt * 32 + (lane & 31);
+                            const int cl = (ch < nch0 ? ch : ch - nch0) * 32 + 16 * j + 8 * (lane >> 5) + e;
+                            const int csrc = ch < nch0 ? c0 : c1;
+                            float v = 0.f;
+                            if (n < cout && cl < csrc) v = w[((size_t)n * ctot + (ch < nch0 ? 0 : c0) + cl) * taps + tap];
+                            uint32_t u;
+                            memcpy(&u, &v, 4);
+                            u += 0x7FFFu + ((u >> 16) & 1u);      // round to nearest even (finite weights)
+                            *o++ = (uint16_t)(u >> 16);
+                        }
+    memset(o, 0, 8192 * sizeof(uint16_t));
+    return CDX_OK;
+}
+
 extern "C" size_t cdx_conv_f16_workspace(const cdx_conv_f16_args*) { return 0; }
 
 extern "C" int32_t cdx_conv_f16_stats_slots(const cdx_conv_f16_args* a) {
@@ -124,14 +151,14 @@ extern "C" int cdx_conv_f16(const cdx_conv_f16_args* a, void*, size_t, cdx_strea
     p.silu = (a->flags & CDX_CONV_SILU) ? 1 : 0;
     p.abl = (a->flags >> 8) & 7;
     p.wunscale = 1.f;
-    p.w = reinterpret_cast<const _Float16*>(a->wpacked);
+    p.w = a->wpacked;
     p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift; p.temb = a->temb; p.temb_ld = a->temb_ld;
     p.residual = a->residual;
     p.out = a->out; p.out_f32 = a->out_is_f32 ? 1 : 0; p.out_ld = a->out_ld; p.stats = a->stats_out;
     int logtw;
     tile_grid(a, logtw, p.tiles_x, p.tiles_y);
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
-    return conv16_dispatch(a->ksize, a->stride, logtw, p, static_cast<hipStream_t>(stream));
+    return conv16_dispatch(a->ksize, a->stride, logtw, (a->flags & CDX_CONV_BF16) != 0, p, static_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -212,7 +239,7 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     p.silu = (a->flags & CDX_CONV_SILU) ? 1 : 0;
     p.abl = 0;
     p.wunscale = a->wsplit_unscale;
-    p.w = reinterpret_cast<const _Float16*>(a->wpacked_split);
+    p.w = a->wpacked_split;
     p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift; p.temb = a->temb; p.temb_ld = a->temb_ld;
     p.residual = a->residual;
     p.out = a->out; p.out_f32 = 1; p.out_ld = a->out_ld; p.stats = a->stats_out;

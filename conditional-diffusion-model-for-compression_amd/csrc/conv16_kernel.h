@@ -35,6 +35,10 @@ namespace cdx {
 
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+__device__ __forceinline__ f32x16 mfma_32x32x16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
 struct Conv16Params {
     const void* src[2];
     int csrc[2];
@@ -44,7 +48,7 @@ struct Conv16Params {
     int ups, gn, silu;
     int abl;         // timing ablation selector (diagnostics)
     float wunscale;  // SPLIT: 2^-s, undoes the host's power-of-two weight scaling (exact); 1 otherwise
-    const _Float16* w;
+    const void* w;           // fragment-packed weights: fp16 (bf16 in BF mode; fp16 hi | lo planes in SPLIT mode)
     const float* bias;
     const float* gscale;
     const float* gshift;
@@ -63,9 +67,12 @@ struct Conv16Params {
 // 64 = halo global loads only for chunks 0 and 1 (later chunks restage stale registers: VALU + LDS-write cost stays)
 // DB = 0: ONE halo image and two barriers per chunk (stride-2 SPLIT tiles, whose 5 x 65-pixel hi|lo image would
 // otherwise leave room for a single workgroup per CU).
-template <int KS_, int STRIDE_, int LOGTW_, int MT_, int PF_ = 3, int ABL_ = 0, int SPLIT_ = 0, int DB_ = 1>
+// BF = 1: bfloat16 storage and v_mfma_f32_32x32x16_bf16 (dtype "bf16"); never together with SPLIT (fp16 hi | lo).
+template <int KS_, int STRIDE_, int LOGTW_, int MT_, int PF_ = 3, int ABL_ = 0, int SPLIT_ = 0, int DB_ = 1, int BF_ = 0>
 struct Conv16Cfg {
-    static constexpr int KS = KS_, STRIDE = STRIDE_, LOGTW = LOGTW_, MT = MT_, PF = PF_, ABL = ABL_, SPLIT = SPLIT_, DB = DB_;
+    static constexpr int KS = KS_, STRIDE = STRIDE_, LOGTW = LOGTW_, MT = MT_, PF = PF_, ABL = ABL_, SPLIT = SPLIT_, DB = DB_, BF = BF_;
+    static_assert(!(SPLIT && BF), "the split operands are fp16");
+    using H = std::conditional_t<BF != 0, __bf16, _Float16>;
     static constexpr int PLANES = SPLIT ? 2 : 1;                   // hi | lo
     static constexpr int KC = 32, PSH = KC * PLANES + 8;           // pixel stride in halves (80 B / 144 B)
     static constexpr int TAPS = KS * KS, PAD = KS / 2;
@@ -93,12 +100,15 @@ __device__ __forceinline__ float silu16_f(float v) {
 template <class C, int STG>
 __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     constexpr bool kGN = STG == 1 || STG == 2, kSILU = STG == 2 || STG == 3;
+    using H = typename C::H;                                       // 16-bit storage / operand type: _Float16 or __bf16
+    using h8 = __attribute__((ext_vector_type(8))) H;
+    using h4 = __attribute__((ext_vector_type(4))) H;
     constexpr int KC = C::KC, PSH = C::PSH, RSH = C::RSH, TAPS = C::TAPS, MT = C::MT, NPASS = C::NPASS, GPC = C::GPC;
     constexpr int PF = C::PF < GPC ? C::PF : GPC;
     // two halo images: chunk c+1 is staged into the other one WHILE chunk c's MFMAs run (one pass per MFMA group), one
     // barrier per chunk -- the f16 MFMA leaves the vector ALU free (unlike the f32 one), so the GroupNorm / SiLU /
     // fp16-rounding work of the staging hides under it instead of standing between two barriers.
-    __shared__ __attribute__((aligned(16))) _Float16 lds_all[(C::DB ? 2 : 1) * C::LDS_HALVES];
+    __shared__ __attribute__((aligned(16))) H lds_all[(C::DB ? 2 : 1) * C::LDS_HALVES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
         } else {
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) {
-                const f16x8 v = __builtin_bit_cast(f16x8, buf_load4(srs, voff[i], so));
+                const h8 v = __builtin_bit_cast(h8, buf_load4(srs, voff[i], so));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pre[i][e] = (float)v[e];
             }
@@ -190,8 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     // Staging is cut into UNITS of half a pass (one pixel slot x 4 channels per thread: ~45 VALU instructions), so that a
     // unit rides on ONE 12-MFMA group without exceeding the issue slots the fp16 MFMA leaves free (a whole pass between two
     // MFMAs was a 128-instruction clump behind an exec-mask branch).  unit u = (pass u >> 1, channel half u & 1).
-    using f16x4s = __attribute__((ext_vector_type(4))) _Float16;
-    f16x4s uo, uol;                                   // the unit being computed (hi | lo)
+    h4 uo, uol;                                   // the unit being computed (hi | lo)
     auto unit_elem = [&](int u, int k) {              // channel k of unit u
         const int i = u >> 1, h = u & 1;
         const bool ok = cvalid && ((vmask >> i) & 1u);
@@ -200,11 +209,11 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
         if constexpr (kSILU) v = silu16_f(v);
         if constexpr (C::SPLIT) {
             v = ok ? __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f) : 0.f;      // saturate instead of inf
-            uo[k] = (_Float16)v;
-            uol[k] = (_Float16)(v - (float)uo[k]);                             // exact difference, rounded once
-        } else uo[k] = (_Float16)(ok ? v : 0.f);
+            uo[k] = (H)v;
+            uol[k] = (H)(v - (float)uo[k]);                             // exact difference, rounded once
+        } else uo[k] = (H)(ok ? v : 0.f);
     };
-    auto unit_store = [&](_Float16* lds, int u) {
+    auto unit_store = [&](H* lds, int u) {
         const int i = u >> 1, h = u & 1;
         const int hp = i * 64 + pl;
         const int hy = hp / C::HW, hx = hp - hy * C::HW;
@@ -213,15 +222,15 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
         const int off = ((i + 1) * 64 <= C::NPIX || hp < C::NPIX) ? hy * RSH + hx * PSH + q * 8 + 4 * h
                                                                    : (pl / C::HW) * RSH + (pl % C::HW) * PSH + KC * C::PLANES;
         const int off_lo = ((i + 1) * 64 <= C::NPIX || hp < C::NPIX) ? off + KC : off + 4;
-        *reinterpret_cast<f16x4s*>(&lds[off]) = uo;
-        if constexpr (C::SPLIT) *reinterpret_cast<f16x4s*>(&lds[off_lo]) = uol;
+        *reinterpret_cast<h4*>(&lds[off]) = uo;
+        if constexpr (C::SPLIT) *reinterpret_cast<h4*>(&lds[off_lo]) = uol;
     };
-    auto write_unit = [&](_Float16* lds, int u) {
+    auto write_unit = [&](H* lds, int u) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) unit_elem(u, k);
         unit_store(lds, u);
     };
-    auto write_pass = [&](_Float16* lds, int i) {
+    auto write_pass = [&](H* lds, int i) {
         write_unit(lds, 2 * i);
         write_unit(lds, 2 * i + 1);
     };
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     const bool nvalid = ntile * 32 < p.Cout;
     // packed weights: [ntile][chunk][tap][j = 0..1][plane][lane][8 halves] -> one group = GH halves (1 KiB per plane)
     constexpr int GH = 512 * C::PLANES;
-    const _Float16* __restrict__ wp = p.w + ((size_t)(nvalid ? ntile : 0) * p.nchunks * TAPS) * (2 * GH) + lane * 8;
+    const H* __restrict__ wp = static_cast<const H*>(p.w) + ((size_t)(nvalid ? ntile : 0) * p.nchunks * TAPS) * (2 * GH) + lane * 8;
 
     f32x16 acc[MT];
 #pragma unroll
@@ -279,14 +288,13 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
         }
     }
 
-    f16x8 ring[PF][C::PLANES];
+    h8 ring[PF][C::PLANES];
 #pragma unroll
     for (int j = 0; j < PF; ++j)
 #pragma unroll
-        for (int pl_ = 0; pl_ < C::PLANES; ++pl_) ring[j][pl_] = *reinterpret_cast<const f16x8*>(wp + j * GH + pl_ * 512);
+        for (int pl_ = 0; pl_ < C::PLANES; ++pl_) ring[j][pl_] = *reinterpret_cast<const h8*>(wp + j * GH + pl_ * 512);
 
     // packed-epilogue layout (see below)
-    using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
     const int q4 = li & 3;
     const int cq = ntile * 32 + (li & ~3);                    // first of this quad's 4 channels
     const bool quad_ok = nvalid && cq < p.Cout;               // (cout is a multiple of 4 or the tail is zero-weighted)
@@ -299,17 +307,17 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
     if (p.nchunks > 1 && !(C::ABL & 2)) issue_loads(1);
     __syncthreads();
-    f16x8 a[MT], al[MT];
+    h8 a[MT], al[MT];
     if constexpr (C::ABL & 8) {                 // ablation: operands read once
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            a[t] = *reinterpret_cast<const f16x8*>(&lds_all[a_base + t * C::RPM * C::STRIDE * RSH]);
-            al[t] = *reinterpret_cast<const f16x8*>(&lds_all[a_base + t * C::RPM * C::STRIDE * RSH + 16]);
+            a[t] = *reinterpret_cast<const h8*>(&lds_all[a_base + t * C::RPM * C::STRIDE * RSH]);
+            al[t] = *reinterpret_cast<const h8*>(&lds_all[a_base + t * C::RPM * C::STRIDE * RSH + 16]);
         }
     }
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        const _Float16* lds = lds_all + (C::DB ? (chunk & 1) * C::LDS_HALVES : 0);
-        _Float16* nxt = lds_all + (C::DB ? ((chunk + 1) & 1) * C::LDS_HALVES : 0);
+        const H* lds = lds_all + (C::DB ? (chunk & 1) * C::LDS_HALVES : 0);
+        H* nxt = lds_all + (C::DB ? ((chunk + 1) & 1) * C::LDS_HALVES : 0);
         const bool more = chunk + 1 < p.nchunks && !(C::ABL & 2);
         if (C::DB && (!nvalid || GPC <= 2)) {
             // a wave without output channels (or a 1x1 layer: two groups per chunk) stages in one go
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
             }
         }
         if (nvalid) {
-            const _Float16* __restrict__ wc = wp + (size_t)chunk * (TAPS * 2 * GH);
+            const H* __restrict__ wc = wp + (size_t)chunk * (TAPS * 2 * GH);
 #pragma unroll
             for (int g = 0; g < GPC; ++g) {
                 // Staging groups (g in [G0, G0 + NU), next chunk exists): the unit's four channel computations are placed
@@ -341,23 +349,23 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
                 if constexpr (!(C::ABL & 8)) {
 #pragma unroll
                     for (int t = 0; t < MT; ++t) {
-                        a[t] = *reinterpret_cast<const f16x8*>(&lds[ab + (t * C::RPM * C::STRIDE + ky) * RSH + kx * PSH + j * 16]);
+                        a[t] = *reinterpret_cast<const h8*>(&lds[ab + (t * C::RPM * C::STRIDE + ky) * RSH + kx * PSH + j * 16]);
                         if constexpr (C::SPLIT)
-                            al[t] = *reinterpret_cast<const f16x8*>(&lds[ab + (t * C::RPM * C::STRIDE + ky) * RSH + kx * PSH + KC + j * 16]);
+                            al[t] = *reinterpret_cast<const h8*>(&lds[ab + (t * C::RPM * C::STRIDE + ky) * RSH + kx * PSH + KC + j * 16]);
                     }
                 }
-                const f16x8 bq = ring[g % PF][0];
-                f16x8 bl;
+                const h8 bq = ring[g % PF][0];
+                h8 bl;
                 if constexpr (C::SPLIT) bl = ring[g % PF][1];
                 if constexpr (!(C::ABL & 4)) {
 #pragma unroll
                     for (int pl_ = 0; pl_ < C::PLANES; ++pl_)      // wraps into the next chunk / tail pad
-                        ring[g % PF][pl_] = *reinterpret_cast<const f16x8*>(wc + (size_t)(g + PF) * GH + pl_ * 512);
+                        ring[g % PF][pl_] = *reinterpret_cast<const h8*>(wc + (size_t)(g + PF) * GH + pl_ * 512);
                 }
                 // MFMA m of the group: term m / MT (hi*hi, lo*hi, hi*lo; lo*lo <= 2^-22 of the product is dropped), tile m % MT
                 auto mfma_at = [&](int m) {
                     const int t = m % MT, term = m / MT;
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 1 ? al[t] : a[t], term == 2 ? bl : bq, acc[t], 0, 0, 0);
+                    acc[t] = mfma_32x32x16(term == 1 ? al[t] : a[t], term == 2 ? bl : bq, acc[t]);
                 };
                 if (kInterleave && stage_here) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -410,8 +418,8 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     const float un = p.wunscale;            // SPLIT: undo the weights' power-of-two scaling (exact); 1 otherwise
     auto epilogue = [&](auto has_res, auto has_stats, auto out32) __attribute__((always_inline)) {
-        using res_t = std::conditional_t<C::SPLIT != 0, f32x4, f16x4>;      // residual: float32 in SPLIT mode
-        using rel_t = std::conditional_t<C::SPLIT != 0, float, _Float16>;
+        using res_t = std::conditional_t<C::SPLIT != 0, f32x4, h4>;      // residual: float32 in SPLIT mode
+        using rel_t = std::conditional_t<C::SPLIT != 0, float, H>;
         res_t rv[MT][4];
         if constexpr (decltype(has_res)::value) {      // one batch of 8/16-byte loads (a load in the last chunk instead
 #pragma unroll                                          // would queue the weight ring behind HBM misses: vmcnt is in-order)
@@ -443,8 +451,8 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
                     if constexpr (decltype(out32)::value) {
                         *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + pix * p.out_ld + cq) = f32x4{x[0], x[1], x[2], x[3]};
                     } else {
-                        *reinterpret_cast<f16x4*>(static_cast<_Float16*>(p.out) + pix * p.out_ld + cq) =
-                            f16x4{(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
+                        *reinterpret_cast<h4*>(static_cast<H*>(p.out) + pix * p.out_ld + cq) =
+                            h4{(H)x[0], (H)x[1], (H)x[2], (H)x[3]};
                     }
                     if constexpr (decltype(has_stats)::value) {
 #pragma unroll
@@ -506,6 +514,6 @@ inline int conv16_launch(const Conv16Params& p, hipStream_t stream) {
     return check_launch();
 }
 
-int conv16_dispatch(int ks, int stride, int logtw, const Conv16Params& p, hipStream_t stream);
+int conv16_dispatch(int ks, int stride, int logtw, bool bf, const Conv16Params& p, hipStream_t stream);
 
 }  // namespace cdx

@@ -27,7 +27,7 @@ def _call(op: str, args, ws_ptr, ws_bytes, t) -> None:
 def _ptr(t, byte_off: int = 0):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.float16) and t.is_contiguous()
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.float16, torch.bfloat16) and t.is_contiguous()
     return t.data_ptr() + byte_off
 
 
@@ -61,15 +61,19 @@ class PackedConv:
 
 
 class PackedConv16:
-    """fp16 fragment image of one convolution's weights (bias stays float32)."""
+    """fp16 (or bfloat16) fragment image of one convolution's weights (bias stays float32)."""
 
-    def __init__(self, w_oihw, bias, c0: int, c1: int = 0, device="cuda"):
+    def __init__(self, w_oihw, bias, c0: int, c1: int = 0, device="cuda", bf16: bool = False):
         import numpy as np
         w = np.asarray(w_oihw, dtype=np.float32)
         self.cout, cin, self.ksize, _ = w.shape
         assert cin == c0 + c1, (cin, c0, c1)
-        self.c0, self.c1 = c0, c1
-        self.w = torch.from_numpy(_abi.pack_conv_weights_f16(w, c0, c1)).to(device)
+        self.c0, self.c1, self.bf16 = c0, c1, bf16
+        self.dtype = torch.bfloat16 if bf16 else torch.float16
+        if bf16:
+            self.w = torch.from_numpy(_abi.pack_conv_weights_bf16(w, c0, c1).view(np.int16)).view(torch.bfloat16).to(device)
+        else:
+            self.w = torch.from_numpy(_abi.pack_conv_weights_f16(w, c0, c1)).to(device)
         self.bias = None if bias is None else torch.as_tensor(np.asarray(bias, np.float32)).to(device)
 
 
@@ -86,14 +90,16 @@ def conv16_args(pc: PackedConv16, src0, src1, out, *, stride=1, upsample=False, 
     assert src1 is None or src1.dtype == src0.dtype
     a.batch, a.hin, a.win, a.hout, a.wout = B, hin, win, hout, wout
     a.cout, a.ksize, a.stride = pc.cout, pc.ksize, stride
-    a.flags = (_abi.CONV_UPSAMPLE2X if upsample else 0) | (_abi.CONV_GN if gn is not None else 0) | (_abi.CONV_SILU if silu else 0)
+    a.flags = (_abi.CONV_UPSAMPLE2X if upsample else 0) | (_abi.CONV_GN if gn is not None else 0) | (_abi.CONV_SILU if silu else 0) | \
+        (_abi.CONV_BF16 if pc.bf16 else 0)
+    assert src0.dtype in (torch.float32, pc.dtype) and out.dtype in (torch.float32, pc.dtype)
     a.wpacked, a.bias = _ptr(pc.w), _ptr(pc.bias)
     if gn is not None:
         a.gn_scale, a.gn_shift = _ptr(gn[0]), _ptr(gn[1])
     if temb is not None:
         a.temb, a.temb_ld = _ptr(temb, 4 * temb_off), temb_ld or temb.shape[-1]
     if residual is not None:
-        assert residual.dtype == torch.float16
+        assert residual.dtype == pc.dtype
     a.residual = _ptr(residual)
     a.out, a.out_is_f32, a.out_ld = _ptr(out), int(out.dtype == torch.float32), out_ld or out.shape[-1]
     assert out.shape[0] == B and out.shape[1] == hout and out.shape[2] == wout and a.out_ld >= pc.cout
@@ -110,7 +116,8 @@ def conv16_stats_buffer(a: _abi.ConvF16Args, device) -> torch.Tensor:
     return buf
 
 
-def conv16(pc: PackedConv16, src0, src1=None, *, out_dtype=torch.float16, want_stats=False, **kw):
+def conv16(pc: PackedConv16, src0, src1=None, *, out_dtype=None, want_stats=False, **kw):
+    out_dtype = out_dtype or pc.dtype
     B, hin, win, _ = src0.shape
     up, stride = kw.get("upsample", False), kw.get("stride", 1)
     hv, wv = (hin * 2, win * 2) if up else (hin, win)
@@ -247,6 +254,9 @@ def attn_args(q, k, v, out, *, batch, nq, nk, heads, head_dim, q_ld, k_ld, v_ld,
     return a
 
 
+ATTN_OP = {torch.float32: "attn_f32", torch.float16: "attn_f16", torch.bfloat16: "attn_bf16"}
+
+
 def attention(q, k, v, heads: int, head_dim: int = 64):
     """q [B,Nq,C], k/v [B,Nk,C] (C = heads*head_dim) -> softmax(q k^T / sqrt(d)) v  [B,Nq,C]; float32 or float16 I/O."""
     B, nq, c = q.shape
@@ -254,7 +264,7 @@ def attention(q, k, v, heads: int, head_dim: int = 64):
     out = torch.empty(B, nq, c, device=q.device, dtype=q.dtype)
     a = attn_args(q, k, v, out, batch=B, nq=nq, nk=nk, heads=heads, head_dim=head_dim,
                   q_ld=c, k_ld=k.shape[-1], v_ld=v.shape[-1], out_ld=c)
-    _call("attn_f16" if q.dtype == torch.float16 else "attn_f32", a, None, 0, q)
+    _call(ATTN_OP[q.dtype], a, None, 0, q)
     return out
 
 

@@ -37,8 +37,8 @@ class _Plan:
         self._ws_need = 0
         self._ws_calls = []      # indices of calls that use the shared workspace
         new = lambda *shape: self._hold(torch.empty(*shape, device=dev, dtype=torch.float32))  # noqa: E731
-        half = net.half                      # fp16 storage / fp16 MFMA for the UNet's activations and weights
-        adt = torch.float16 if half else torch.float32
+        half = net.half                      # 16-bit storage (fp16 / bf16) and 16-bit MFMA for the UNet's activations and weights
+        adt = net.adt
         newa = lambda *shape: self._hold(torch.empty(*shape, device=dev, dtype=adt))  # noqa: E731  (activations)
 
         self.xin_ld = _pad4(g.cin_total)
@@ -111,7 +111,7 @@ class _Plan:
             Bn, hh, ww, c = x.shape
             qkv = conv(n + ".qkv", x, gn=gn(n + ".norm", x))
             o = newa(Bn, hh, ww, c)
-            self._add("attn_f16" if half else "attn_f32", ops.attn_args(qkv, qkv, qkv, o, batch=Bn, nq=hh * ww, nk=hh * ww,
+            self._add(ops.ATTN_OP[adt], ops.attn_args(qkv, qkv, qkv, o, batch=Bn, nq=hh * ww, nk=hh * ww,
                                                  heads=c // cfg["head_dim"], head_dim=cfg["head_dim"],
                                                  q_ld=3 * c, k_ld=3 * c, v_ld=3 * c, out_ld=c, k_off=c, v_off=2 * c))
             return conv(n + ".proj", o, residual=x, normed_later=True)
@@ -123,7 +123,7 @@ class _Plan:
             kv = conv(n + ".kv", self.ctx)                       # [B, lh, lw, 2c]
             L = self.ctx.shape[1] * self.ctx.shape[2]
             o = newa(Bn, hh, ww, c)
-            self._add("attn_f16" if half else "attn_f32", ops.attn_args(q, kv, kv, o, batch=Bn, nq=hh * ww, nk=L,
+            self._add(ops.ATTN_OP[adt], ops.attn_args(q, kv, kv, o, batch=Bn, nq=hh * ww, nk=L,
                                                  heads=c // cfg["head_dim"], head_dim=cfg["head_dim"],
                                                  q_ld=c, k_ld=2 * c, v_ld=2 * c, out_ld=c, v_off=c))
             return conv(n + ".proj", o, residual=x, normed_later=True)
@@ -215,7 +215,10 @@ class UNet:
         _abi.lib()   # fail loudly now if the extension is missing
         self.fuse_gn_stats = fuse_gn_stats   # False: every GroupNorm re-reads its input (cdx_gn_stats_f32)
         self.split = split                   # float32 layers carry the fp16 hi|lo weight image (CDX_TILE_SPLIT); False: f32-MFMA kernels only
-        self.half = validate_unet_config(cfg)["dtype"] == "fp16"
+        dt = validate_unet_config(cfg)["dtype"]
+        self.half = dt in ("fp16", "bf16")
+        self.bf16 = dt == "bf16"
+        self.adt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[dt]
         if not torch.cuda.is_available():
             raise RuntimeError("UNet (HIP backend) needs a GPU; there is no CPU fallback in the product path")
         self.cfg = validate_unet_config(cfg)
@@ -253,7 +256,7 @@ class UNet:
                 for b in res_blocks:    # up-path ResBlocks read (x, skip) as two sources
                     if b.skip_ch and base in (b.name + ".conv1", b.name + ".skip"):
                         c0, c1 = b.cin - b.skip_ch, b.skip_ch
-                self.convs[base] = (ops.PackedConv16(w, bias, c0, c1, self.device) if self.half else
+                self.convs[base] = (ops.PackedConv16(w, bias, c0, c1, self.device, bf16=self.bf16) if self.half else
                                     ops.PackedConv(w, bias, c0, c1, self.device, split=split))
             elif ".norm" in name or name.startswith("temb."):
                 self.dev[name] = up(P[name])
@@ -261,7 +264,7 @@ class UNet:
             if b.kind == "xattn":   # kv projection of the context tokens runs as a 1x1 convolution
                 w = P[b.name + ".kv.weight"]
                 self.convs[b.name + ".kv"] = (ops.PackedConv16 if self.half else ops.PackedConv)(
-                    w[:, :, None, None], P[b.name + ".kv.bias"], w.shape[1], 0, self.device, **({} if self.half else {"split": split}))
+                    w[:, :, None, None], P[b.name + ".kv.bias"], w.shape[1], 0, self.device, **({"bf16": self.bf16} if self.half else {"split": split}))
         # all ResBlock temb projections as one [sum(cout), temb_dim] linear
         self.tproj_off, off = {}, 0
         for b in res_blocks:

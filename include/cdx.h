@@ -52,7 +52,8 @@ const char* cdx_strerror(int status);
 enum {
     CDX_CONV_UPSAMPLE2X = 1, /* sources are nearest-upsampled x2 before the conv (U5) */
     CDX_CONV_GN = 2,         /* apply x*gn_scale[b][c] + gn_shift[b][c] while staging (U2) */
-    CDX_CONV_SILU = 4        /* then x * sigmoid(x) (U2) */
+    CDX_CONV_SILU = 4,       /* then x * sigmoid(x) (U2) */
+    CDX_CONV_BF16 = 8        /* cdx_conv_f16 only: the 16-bit tensors and weights are bfloat16 (v_mfma_f32_32x32x16_bf16) */
 };
 
 #define CDX_CONV_KC 32 /* input-channel chunk of the packed weight layout */
@@ -174,6 +175,8 @@ int32_t cdx_conv_f16_stats_slots(const cdx_conv_f16_args* a);
  * + 16 KiB zero pad.  Sizes are in halves. */
 size_t cdx_conv_f16_packed_halves(int32_t c0, int32_t c1, int32_t cout, int32_t ksize);
 int cdx_conv_pack_weights_f16(const float* w_oihw, int32_t c0, int32_t c1, int32_t cout, int32_t ksize, cdx_half* packed);
+/* the same layout in bfloat16 (round to nearest even) for launches with CDX_CONV_BF16 */
+int cdx_conv_pack_weights_bf16(const float* w_oihw, int32_t c0, int32_t c1, int32_t cout, int32_t ksize, uint16_t* packed);
 
 /* ------------------------------------------------------------------------------------------
  * U2: GroupNorm statistics of cat[src0, src1] -> per-(batch, channel) scale / shift
@@ -235,6 +238,9 @@ size_t cdx_attn_f32_workspace(const cdx_attn_args* a);
 /* attention core with fp16 q/k/v/out (float32 softmax and accumulation); same arguments as cdx_attn_f32 */
 int cdx_attn_f16(const cdx_attn_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
 size_t cdx_attn_f16_workspace(const cdx_attn_args* a);
+/* q / k / v / out in bfloat16 (v_mfma_f32_32x32x16_bf16) */
+int cdx_attn_bf16(const cdx_attn_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_attn_bf16_workspace(const cdx_attn_args* a);
 
 /* ------------------------------------------------------------------------------------------
  * U1: small-M linear  out[m][n] = sum_k act(x[m][k]) * w[n][k] + bias[n]   (F.linear)

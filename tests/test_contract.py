@@ -43,7 +43,7 @@ def test_config_validation():
     with pytest.raises(ValueError):
         cdx.unet_config(base_channels=48)         # 48 % 32 groups
     with pytest.raises(ValueError):
-        cdx.unet_config(dtype="bf16")
+        cdx.unet_config(dtype="fp8")
     assert cdx.unet_config(dtype="fp16")["dtype"] == "fp16"
     c5, r5 = cdx.named_config("cfg5")
     assert c5["dtype"] == "fp16" and c5["image_size"] == 256 and r5["image"] == 1024 and r5["steps"] == 50
