@@ -15,3 +15,7 @@ from .tiling import tile_plan, tile_origins
 from .shard import shard_range, decode_shard, timed_region
 
 __all__ += ["UNet", "Sampler", "sample", "ops", "_abi", "shard", "params", "shard_range", "decode_shard", "timed_region", "tiling", "tile_plan", "tile_origins"]
+from . import context
+from .context import ContextNet, context_config, init_context_params, synthetic_latent, decode_latent
+
+__all__ += ["context", "ContextNet", "context_config", "init_context_params", "synthetic_latent", "decode_latent"]

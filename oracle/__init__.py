@@ -16,7 +16,8 @@ from .unet_ref import unet_forward_ref, timestep_embedding_ref
 from .sampler_ref import sample_ref, make_schedule_ref, step_coefficients_ref
 from .rng_ref import normal_ref, uniform_ref, stream_key_ref
 from .tiling_ref import sample_tiled_ref, blend_ref, origins_ref
+from .context_ref import context_forward_ref
 
 __all__ = ["unet_forward_ref", "timestep_embedding_ref", "sample_ref", "make_schedule_ref",
            "step_coefficients_ref", "normal_ref", "uniform_ref", "stream_key_ref",
-           "sample_tiled_ref", "blend_ref", "origins_ref"]
+           "sample_tiled_ref", "blend_ref", "origins_ref", "context_forward_ref"]

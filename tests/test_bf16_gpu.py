@@ -113,7 +113,7 @@ def test_attention_16bit_mfma(cdx_mod, dtype, tol):
                    cross_attn_resolutions=(64, 32), context_dim=96, num_res_blocks=1)),
 ])
 def test_bf16_unet_forward_vs_fp32_oracle(cdx_mod, record, name, over):
-    """bf16 storage against the float64 oracle: stated tolerance 6e-2 of the output scale (fp16: 1e-2; measured and recorded)."""
+    """bf16 storage against the float64 oracle: stated tolerance 3e-2 of the output scale (measured 1.0-1.4e-2; fp16: 1e-2 stated, 1.5e-3 measured)."""
     import oracle
     cfg32 = cdx_mod.unet_config(**over)
     cfg16 = cdx_mod.unet_config(**over, dtype="bf16")
@@ -126,7 +126,7 @@ def test_bf16_unet_forward_vs_fp32_oracle(cdx_mod, record, name, over):
     got = cdx_mod.UNet(cfg16, params).forward(x.cuda(), t.cuda(), cond.cuda()).cpu()
     err = (got.double() - want).abs().max().item() / want.abs().max().item()
     record("bf16_unet_forward_" + name, rel_max_err=err, rms_rel=((got.double() - want).pow(2).mean().sqrt() / want.abs().max()).item())
-    assert err <= 6e-2
+    assert err <= 3e-2
 
 
 def test_bf16_sampler_vs_fp32_oracle(cdx_mod, record):
