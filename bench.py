@@ -105,16 +105,20 @@ def kernel_model(variant) -> dict:
     if tile.startswith("wino"):
         # Winograd F(2x2,3x3): 16 transform-domain multiply-adds per 2x2 output tile where the direct algorithm needs 36
         return {"name": "conv_wino8_kernel<WinoCfg<2,0>> (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
-                "executed_per_algorithmic": 1.0 / 2.25, "peak": FP32_MFMA_PEAK_TFLOPS, "wino": True, "flops_per_mfma_cycle": 64.0}
+                "executed_per_algorithmic": 1.0 / 2.25, "peak": FP32_MFMA_PEAK_TFLOPS, "wino": True, "flops_per_mfma_cycle": 64.0,
+                "pmc_pattern": "conv_wino8_kernel"}
     if tile.startswith("split"):
         # float32 product on the fp16 matrix pipe: hi*hi + lo*hi + hi*lo = 3 fp16 MFMA FLOPs per algorithmic FLOP
         return {"name": "conv16_kernel<Conv16Cfg<..., SPLIT>> (f32 conv as 3 x v_mfma_f32_32x32x16_f16 on hi|lo split operands)",
-                "executed_per_algorithmic": 3.0, "peak": FP16_MFMA_PEAK_TFLOPS, "wino": False, "flops_per_mfma_cycle": 1024.0}
+                "executed_per_algorithmic": 3.0, "peak": FP16_MFMA_PEAK_TFLOPS, "wino": False, "flops_per_mfma_cycle": 1024.0,
+                # rocprofv3 kernel-name substring of this variant (every staging mode STG of it): KS, ST, log2TW, MT, PF, ABL, SPLIT, DB, BF
+                "pmc_pattern": "Conv16Cfg<%d, %d, %d, %d, 3, 0, 1, %d, 0>" % (variant[0], variant[1], variant[2], 2 if (variant[1] == 2 or variant[2] < 5) else 4, 0 if variant[1] == 2 else 1)}
     if tile.startswith("f16"):
         return {"name": "conv16_kernel<Conv16Cfg> (v_mfma_f32_32x32x16_f16)", "executed_per_algorithmic": 1.0,
-                "peak": FP16_MFMA_PEAK_TFLOPS, "wino": False, "flops_per_mfma_cycle": 1024.0}
+                "peak": FP16_MFMA_PEAK_TFLOPS, "wino": False, "flops_per_mfma_cycle": 1024.0,
+                "pmc_pattern": "Conv16Cfg<%d, %d, %d, %d, 3, 0, 0, 1, " % (variant[0], variant[1], variant[2], 2 if variant[1] == 2 else 4)}
     return {"name": "conv_kernel<ConvCfg> (direct implicit GEMM on v_mfma_f32_32x32x2_f32)", "executed_per_algorithmic": 1.0,
-            "peak": FP32_MFMA_PEAK_TFLOPS, "wino": False, "flops_per_mfma_cycle": 64.0}
+            "peak": FP32_MFMA_PEAK_TFLOPS, "wino": False, "flops_per_mfma_cycle": 64.0, "pmc_pattern": "conv_kernel<cdx::ConvCfg<%d, %d, %d, " % variant[:3]}
 
 
 def measure_dominant_kernel(plan, torch, reps=3):
@@ -173,14 +177,15 @@ def measure_dominant_kernel(plan, torch, reps=3):
     # the kernels (csrc hash) and for THIS kernel; otherwise traffic stays null and the stale digest is named.
     sha = csrc_sha16()
     roof["csrc_sha16"] = sha
+    roof["pmc_pattern"] = km["pmc_pattern"]
     for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-        if not (name.endswith("_traffic.json")):
+        if "_traffic" not in name or not name.endswith(".json"):
             continue
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
             continue
-        same_kernel = tr.get("kernel", "").split("<")[0] == km["name"].split("<")[0]
+        same_kernel = tr.get("pattern") == km["pmc_pattern"]
         if same_kernel and tr.get("csrc_sha16") == sha:
             roof["traffic"] = round(tr["hbm_bytes_per_launch"])
             roof["traffic_over_algorithmic"] = round(tr["hbm_bytes_per_launch"] / roof["algorithmic_bytes_per_launch"], 3)

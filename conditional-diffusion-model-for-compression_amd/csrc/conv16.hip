@@ -215,7 +215,8 @@ namespace cdx {
 // Is this cdx_conv_f32 launch one the SPLIT kernel is built for?  (conv.hip asks before choosing the tile.)
 bool conv_split_ok(const cdx_conv_args* a) {
     if (!a->wpacked_split || !aligned16(a->wpacked_split) || !(a->wsplit_unscale > 0.f)) return false;
-    if (a->wout < 16 || a->cout <= 4) return false;
+    if (a->wout < 8 || a->cout <= 4) return false;                                    // (below 8 pixels: f32-MFMA split-K tiles)
+    if (a->stride == 2 && a->wout < 16) return false;
     if ((a->c0 % 8) != 0 || (a->c1 % 8) != 0) return false;                           // the loader moves 8-channel octets                                   // (8^2 and below: f32-MFMA split-K tiles)
     if (a->stride == 2 && a->ksize != 3) return false;
     if ((a->out_ld % 4) != 0 || a->out_ld < ((a->cout + 3) & ~3)) return false;      // outputs move as 4-channel vectors
@@ -243,7 +244,10 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift; p.temb = a->temb; p.temb_ld = a->temb_ld;
     p.residual = a->residual;
     p.out = a->out; p.out_f32 = 1; p.out_ld = a->out_ld; p.stats = a->stats_out;
-    const int logtw = a->wout >= 32 ? 5 : 4, tw = 1 << logtw, th = (a->stride == 2 ? 64 : 128) / tw;
+    // tile: 128 pixels x 128 channels at >= 32 pixels wide; 64 x 128 below (16^2 / 8^2 levels: twice the workgroups -- at
+    // batch 16 a 128-pixel tile leaves half of the CUs idle there) and for stride 2
+    const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : 3, tw = 1 << logtw;
+    const int bm = (a->stride == 2 || a->wout < 32) ? 64 : 128, th = bm / tw;
     p.tiles_x = ceil_div(a->wout, tw);
     p.tiles_y = ceil_div(a->hout, th);
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
@@ -252,8 +256,12 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
         return conv16_launch<Conv16Cfg<3, 2, 4, 2, 3, 0, 1, 0>>(p, stream);
     }
     if (logtw == 4) {
-        if (a->ksize == 3) return conv16_launch<Conv16Cfg<3, 1, 4, 4, 3, 0, 1>>(p, stream);
-        return conv16_launch<Conv16Cfg<1, 1, 4, 4, 3, 0, 1>>(p, stream);
+        if (a->ksize == 3) return conv16_launch<Conv16Cfg<3, 1, 4, 2, 3, 0, 1>>(p, stream);
+        return conv16_launch<Conv16Cfg<1, 1, 4, 2, 3, 0, 1>>(p, stream);
+    }
+    if (logtw == 3) {
+        if (a->ksize == 3) return conv16_launch<Conv16Cfg<3, 1, 3, 2, 3, 0, 1>>(p, stream);
+        return conv16_launch<Conv16Cfg<1, 1, 3, 2, 3, 0, 1>>(p, stream);
     }
 #ifdef CDX_TUNING
     if (a->ksize == 3 && variant) {      // timing ablations / tuning variants (tools/conv_bench.py --tiles 60..)

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
                 // ~60 VALU instructions as one clump in front of the group's first MFMA (and sched_group_barrier pipelines
                 // did not move them).  A quarter = 3 MFMAs (96 matrix-pipe cycles) + ~14 VALU instructions.
                 constexpr int NM = MT * (C::SPLIT ? 3 : 1);                  // MFMAs per group
-                constexpr bool kInterleave = C::DB && GPC > 2 && (NM % 4) == 0 && !(C::ABL & 128);
+                constexpr bool kInterleave = C::DB && GPC > 2 && NM >= 4 && !(C::ABL & 128);
                 // (compile-time: in the LAST chunk the unit restages stale registers into the idle image -- harmless, and it
                 // keeps the unrolled chunk body free of runtime branches, which would cut it into small scheduling regions)
                 const bool stage_here = C::DB && GPC > 2 && !(C::ABL & 2) && g >= G0 && g < G0 + NU;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
 #pragma unroll
-                        for (int m = k * (NM / 4); m < (k + 1) * (NM / 4); ++m) mfma_at(m);
+                        for (int m = k * NM / 4; m < (k + 1) * NM / 4; ++m) mfma_at(m);      // (NM = 6: quarters of 1, 2, 1, 2)
                         unit_elem(g - G0, k);
                         __builtin_amdgcn_sched_barrier(0);
                     }

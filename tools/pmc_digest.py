@@ -52,8 +52,9 @@ def traffic(argv):
     gw = [v for k, v in write if "gauss_fill" in k]
     res = {
         "kernel": name.split("(")[0],
+        "pattern": pat,
         "csrc_sha16": sha(),
-        "population": "all %d launches of the kernel in the profiled command" % len(f),
+        "population": "all %d launches of kernels whose name contains the pattern, in the profiled command" % len(f),
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py "
                    "--steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-sample-call (two separate passes)",
         "fetch_size_bytes_raw": 1024.0 * sum(f) / len(f),
@@ -79,8 +80,9 @@ def mfma(argv):
     allb, allg = sum(v for _, v in busy), sum(v for _, v in gui)
     res = {
         "kernel": name.split("(")[0],
+        "pattern": pat,
         "csrc_sha16": sha(),
-        "population": "all %d launches of the kernel in the profiled command" % len(b),
+        "population": "all %d launches of kernels whose name contains the pattern, in the profiled command" % len(b),
         "command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -- python3 bench.py "
                    "--steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-sample-call",
         "sq_valu_mfma_busy_cycles_per_launch": sum(b) / len(b),
