@@ -11,6 +11,7 @@ using namespace cdx;
 namespace cdx {
 bool conv_split_ok(const cdx_conv_args* a);                       // conv16.hip
 int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant = 0);
+int conv_split_slots_per_tile(const cdx_conv_args* a);
 }  // namespace cdx
 
 namespace {
@@ -144,7 +145,7 @@ Tile select_tile(const cdx_conv_args* a) {
     // Layers at >= 32 pixels wide: the float32 product on the FP16 matrix pipe with split operands (3 MFMAs of 32 cycles
     // per 16 channels against 8 x 64 for the f32-input MFMA): same float32-level error, 2.4x less matrix-pipe time than
     // even the Winograd kernel.  Needs the wpacked_split image; otherwise the float32-MFMA kernels below are used.
-    if (conv_split_ok(a)) return Tile{WCFG_SPLIT, (a->stride == 2 || a->wout < 32) ? 64 : 128, 128, 1};
+    if (conv_split_ok(a)) return Tile{WCFG_SPLIT, (a->stride == 2 || a->wout < 32) ? 64 : 128, 128, conv_split_slots_per_tile(a)};
     if (a->ksize == 3) {
         if (hw <= kSplitKMaxPixels) t = tile_of(a->stride == 1 && hw >= 256 ? WCFG_S64 : WCFG_S32);
         else if (cin8_ok(a)) t = tile_of(WCFG_CIN8);

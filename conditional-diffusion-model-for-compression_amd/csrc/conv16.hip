@@ -130,7 +130,7 @@ extern "C" int32_t cdx_conv_f16_stats_slots(const cdx_conv_f16_args* a) {
     if (validate(a)) return 0;
     int logtw, tx, ty;
     tile_grid(a, logtw, tx, ty);
-    return tx * ty;
+    return tx * ty * (conv16_tail_2x2(a->cout, a->stride == 2 ? 2 : 4) ? 2 : 1);
 }
 
 extern "C" int cdx_conv_f16(const cdx_conv_f16_args* a, void*, size_t, cdx_stream_t stream) {
@@ -155,6 +155,7 @@ extern "C" int cdx_conv_f16(const cdx_conv_f16_args* a, void*, size_t, cdx_strea
     p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift; p.temb = a->temb; p.temb_ld = a->temb_ld;
     p.residual = a->residual;
     p.out = a->out; p.out_f32 = a->out_is_f32 ? 1 : 0; p.out_ld = a->out_ld; p.stats = a->stats_out;
+    p.stats_wm = conv16_tail_2x2(a->cout, a->stride == 2 ? 2 : 4) ? 2 : 1;
     int logtw;
     tile_grid(a, logtw, p.tiles_x, p.tiles_y);
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
@@ -215,13 +216,19 @@ namespace cdx {
 // Is this cdx_conv_f32 launch one the SPLIT kernel is built for?  (conv.hip asks before choosing the tile.)
 bool conv_split_ok(const cdx_conv_args* a) {
     if (!a->wpacked_split || !aligned16(a->wpacked_split) || !(a->wsplit_unscale > 0.f)) return false;
-    if (a->wout < 8 || a->cout <= 4) return false;                                    // (below 8 pixels: f32-MFMA split-K tiles)
-    if (a->stride == 2 && a->wout < 16) return false;
+    // below 16 pixels wide the f32-MFMA split-K tiles stay: measured at 8^2 x 512 ch, batch 16, the 64-pixel split tile
+    // gives only 64 workgroups of 16 serial chunks each -- 1.12 ms per forward against 1.06 (3x3) and 0.17 against 0.15 (1x1)
+    if (a->wout < 16 || a->cout <= 4) return false;
     if ((a->c0 % 8) != 0 || (a->c1 % 8) != 0) return false;                           // the loader moves 8-channel octets                                   // (8^2 and below: f32-MFMA split-K tiles)
     if (a->stride == 2 && a->ksize != 3) return false;
     if ((a->out_ld % 4) != 0 || a->out_ld < ((a->cout + 3) & ~3)) return false;      // outputs move as 4-channel vectors
     if ((a->residual || a->stats_out) && (a->cout % 4) != 0) return false;
     return true;
+}
+
+// GroupNorm-sum slots per spatial tile of a SPLIT launch: 2 when the 128-pixel tile's last channel block runs 2 x 2
+int conv_split_slots_per_tile(const cdx_conv_args* a) {
+    return conv16_tail_2x2(a->cout, (a->stride == 2 || a->wout < 32) ? 2 : 4) ? 2 : 1;
 }
 
 int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
@@ -244,6 +251,7 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift; p.temb = a->temb; p.temb_ld = a->temb_ld;
     p.residual = a->residual;
     p.out = a->out; p.out_f32 = 1; p.out_ld = a->out_ld; p.stats = a->stats_out;
+    p.stats_wm = conv_split_slots_per_tile(a);
     // tile: 128 pixels x 128 channels at >= 32 pixels wide; 64 x 128 below (16^2 / 8^2 levels: twice the workgroups -- at
     // batch 16 a 128-pixel tile leaves half of the CUs idle there) and for stride 2
     const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : 3, tw = 1 << logtw;

@@ -59,8 +59,12 @@ struct Conv16Params {
     int out_f32;
     int out_ld;
     double* stats;
+    int stats_wm;            // GroupNorm-sum slots per spatial tile (2 when the layer's last channel block runs the 2 x 2 layout)
     int tiles_x, tiles_y;
 };
+
+// channels left for the last 128-channel block; the 2 x 2 wave layout serves it when they fit two N-tiles
+__host__ __device__ inline bool conv16_tail_2x2(int cout, int mt) { const int rem = cout % 128; return mt == 4 && rem > 0 && rem <= 64; }
 
 // ABL: timing-only ablations (wrong results; libcdx_tune.so only): 1 = no epilogue, 2 = stage only the first chunk,
 // 4 = no weight refills, 8 = no LDS operand reads (registers reused), 16 = no residual loads, 32 = no GroupNorm sums,
@@ -97,22 +101,26 @@ __device__ __forceinline__ float silu16_f(float v) {
 
 // STG (compile-time staging mode, chosen at launch from the GN / SiLU flags -- a runtime flag costs a v_cndmask per element
 // and flag in the staging code): 0 = plain, 1 = GroupNorm scale/shift, 2 = GroupNorm + SiLU, 3 = SiLU only.
-template <class C, int STG>
-__global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
+// WM (wave layout of the 128-pixel x N tile): 1 = 1 x 4 (every wave owns all MT M-tiles of one 32-channel N-tile: 128
+// channels per workgroup); 2 = 2 x 2 (wave = half of the M-tiles x one of TWO N-tiles: 64 channels per workgroup) -- used for
+// the LAST channel block of a layer whose channel count leaves at most 64 channels there (cout = 192: 128 + 64), where the
+// 1 x 4 layout would leave two of the four waves without output channels.
+template <class C, int STG, int WM>
+__device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H* lds_all) {
     constexpr bool kGN = STG == 1 || STG == 2, kSILU = STG == 2 || STG == 3;
     using H = typename C::H;                                       // 16-bit storage / operand type: _Float16 or __bf16
     using h8 = __attribute__((ext_vector_type(8))) H;
     using h4 = __attribute__((ext_vector_type(4))) H;
-    constexpr int KC = C::KC, PSH = C::PSH, RSH = C::RSH, TAPS = C::TAPS, MT = C::MT, NPASS = C::NPASS, GPC = C::GPC;
+    constexpr int KC = C::KC, PSH = C::PSH, RSH = C::RSH, TAPS = C::TAPS, NPASS = C::NPASS, GPC = C::GPC;
+    constexpr int WN = 4 / WM;
+    constexpr int MT = C::MT / WM;                                 // M-tiles PER WAVE
+    static_assert(C::MT % WM == 0 && (MT * 32) % C::TW == 0, "a wave's M-tiles must be whole tile rows");
     constexpr int PF = C::PF < GPC ? C::PF : GPC;
-    // two halo images: chunk c+1 is staged into the other one WHILE chunk c's MFMAs run (one pass per MFMA group), one
-    // barrier per chunk -- the f16 MFMA leaves the vector ALU free (unlike the f32 one), so the GroupNorm / SiLU /
-    // fp16-rounding work of the staging hides under it instead of standing between two barriers.
-    __shared__ __attribute__((aligned(16))) H lds_all[(C::DB ? 2 : 1) * C::LDS_HALVES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv % WN, wm = wv / WN;
 
     int bx = blockIdx.x;
     const int tx = bx % p.tiles_x;
@@ -120,6 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     const int ty = bx % p.tiles_y;
     const int b = bx / p.tiles_y;
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+    const int oy0w = oy0 + ((wm * MT * 32) >> C::LOGTW);           // first output row of THIS wave's M-tiles
     const int iy0 = oy0 * C::STRIDE - C::PAD, ix0 = ox0 * C::STRIDE - C::PAD;
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
 
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
 
     // ---- MFMA operand addressing ----
     const int li = lane & 31, lh = lane >> 5;
-    const int a_base = ((li >> C::LOGTW) * C::STRIDE) * RSH + ((li & (C::TW - 1)) * C::STRIDE) * PSH + lh * 8;
+    const int a_base = ((li >> C::LOGTW) * C::STRIDE + wm * MT * C::RPM * C::STRIDE) * RSH + ((li & (C::TW - 1)) * C::STRIDE) * PSH + lh * 8;
     const int ntile = blockIdx.y * 4 + wn;
     const bool nvalid = ntile * 32 < p.Cout;
     // packed weights: [ntile][chunk][tap][j = 0..1][plane][lane][8 halves] -> one group = GH halves (1 KiB per plane)
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
             if (p.residual && !(C::ABL & 16)) {
                 // rows past the image end / columns past the row end read other (or no: bounded resource) pixels; those
                 // accumulators are never stored
-                const size_t first = (((size_t)b * p.Hout + oy0) * p.Wout + ox0) * p.Cout;
+                const size_t first = (((size_t)b * p.Hout + oy0w) * p.Wout + ox0) * p.Cout;
                 const size_t left = ((size_t)p.B * p.Hout * p.Wout * p.Cout - first) * 4;
                 const __amdgpu_buffer_rsrc_t rr = buf_rsrc(static_cast<const float*>(p.residual) + first,
                                                            left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)left);
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int m = t * 32 + 8 * k + q4 + 4 * lh;
-                    const int oy = min(oy0 + (m >> C::LOGTW), p.Hout - 1), ox = min(ox0 + (m & (C::TW - 1)), p.Wout - 1);
+                    const int oy = min(oy0w + (m >> C::LOGTW), p.Hout - 1), ox = min(ox0 + (m & (C::TW - 1)), p.Wout - 1);
                     rv[t][k] = *reinterpret_cast<const res_t*>(static_cast<const rel_t*>(p.residual) +
                                                                (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + (quad_ok ? cq : 0));
                 }
@@ -441,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
                 for (int c = 0; c < 4; ++c) x[c] = C::SPLIT ? acc[t][4 * k + c] * un : acc[t][4 * k + c] + add;
                 quad_transpose(x, q4);                        // now: pixel 8k + q4 (+4 lh) of tile t, channels cq..cq+3
                 const int m = t * 32 + 8 * k + q4 + 4 * lh;
-                const int oy = oy0 + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
+                const int oy = oy0w + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
                 if (quad_ok && oy < p.Hout && ox < p.Wout) {
                     const size_t pix = ((size_t)b * p.Hout + oy) * p.Wout + ox;
                     if constexpr (decltype(has_res)::value) {
@@ -488,8 +497,10 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
             s2[c] += __shfl_xor(s2[c], 32);
         }
         if (lh == 0 && q4 == 0 && quad_ok) {
-            const int slot = ty * p.tiles_x + tx;
-            const int nslots = p.tiles_y * p.tiles_x;
+            // p.stats_wm slots per tile: a layer with a 2 x 2 last block has two (its 1 x 4 blocks fill the first, the
+            // second stays zero as allocated)
+            const int slot = (ty * p.tiles_x + tx) * p.stats_wm + (WM == 2 ? wm : 0);
+            const int nslots = p.tiles_y * p.tiles_x * p.stats_wm;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (cq + c < p.Cout) {
@@ -500,6 +511,21 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
             }
         }
     }
+}
+
+template <class C, int STG>
+__global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
+    // two halo images: chunk c+1 is staged into the other one WHILE chunk c's MFMAs run (one unit per MFMA group), one
+    // barrier per chunk (DB = 0: one image, two barriers)
+    __shared__ __attribute__((aligned(16))) typename C::H lds_all[(C::DB ? 2 : 1) * C::LDS_HALVES];
+    if constexpr (C::MT == 4) {
+        // block-uniform: the last channel block of a layer with <= 64 channels left runs the 2 x 2 wave layout
+        if (blockIdx.y == gridDim.y - 1 && conv16_tail_2x2(p.Cout, C::MT)) {
+            conv16_body<C, STG, 2>(p, lds_all);
+            return;
+        }
+    }
+    conv16_body<C, STG, 1>(p, lds_all);
 }
 
 template <class C>

@@ -44,7 +44,7 @@ CASES = [  # (B, Cin, Cout, H, W, ksize, stride, upsample)
     (2, 32, 128, 32, 32, 3, 1, False), (1, 64, 160, 16, 16, 3, 1, False), (2, 128, 64, 8, 8, 3, 1, False),
     (3, 32, 32, 4, 4, 3, 1, False), (1, 40, 48, 40, 24, 3, 1, False), (2, 64, 96, 32, 32, 1, 1, False),
     (2, 32, 128, 32, 32, 3, 2, False), (1, 64, 64, 18, 10, 3, 2, False), (2, 32, 128, 16, 16, 3, 1, True),
-    (1, 96, 128, 64, 64, 3, 1, False),
+    (1, 96, 128, 64, 64, 3, 1, False), (2, 64, 192, 32, 32, 3, 1, False), (1, 64, 320, 36, 40, 1, 1, False),     # 128 + 64 channels: 2 x 2 last block
 ]
 
 

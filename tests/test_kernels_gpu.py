@@ -60,6 +60,10 @@ CONV_CASES = [
     (2, 32, 128, 16, 16, 3, 1, True),      # nearest-2x upsample fused
     (1, 64, 64, 5, 7, 3, 1, True),         # upsample, ragged
     (1, 96, 128, 64, 64, 3, 1, False),     # 3 chunks, multiple tiles in x and y
+    (2, 64, 192, 32, 32, 3, 1, False),     # cout = 128 + 64 (cfg4's widths): the split tile's last channel block runs the 2 x 2 wave layout
+    (1, 128, 320, 36, 40, 3, 1, False),    # 2 x 128 + 64, ragged
+    (1, 64, 192, 32, 64, 1, 1, False),     # 1x1, 128 + 64
+    (1, 64, 160, 40, 40, 3, 1, False),     # 128 + 32: 2 x 2 layout with one empty N-tile
 ]
 
 
@@ -67,10 +71,10 @@ def tiles_for(k, s, wout=0, cout=999, cin=1024):
     """Every tile shape built for this ksize / stride (include/cdx.h CDX_TILE_*), plus -1 = the library's pick.
     Tile 7 = Winograd F(2x2,3x3) (3x3 stride 1, output width >= 32)."""
     if k == 1:
-        return (-1, 0, 1, 2) + ((5, 6) if wout < 32 else ()) + ((11,) if wout >= 8 and cout > 4 and cin % 8 == 0 else ())
+        return (-1, 0, 1, 2) + ((5, 6) if wout < 32 else ()) + ((11,) if wout >= 16 and cout > 4 and cin % 8 == 0 else ())
     if s == 2:
         return (-1, 3, 4, 5) + ((11,) if wout >= 16 and cout > 4 and cin % 8 == 0 else ())
-    return (-1, 0, 1, 2, 5, 6) + ((8, 9) if wout >= 32 and cout <= 4 else ()) + ((10,) if wout >= 32 and cin <= 8 and cout > 4 else ()) + ((7,) if wout >= 32 else ()) + ((11,) if wout >= 8 and cout > 4 and cin % 8 == 0 else ())     # 7 = Winograd F(2x2,3x3); 11 = split-fp16 operands on the fp16 matrix pipe
+    return (-1, 0, 1, 2, 5, 6) + ((8, 9) if wout >= 32 and cout <= 4 else ()) + ((10,) if wout >= 32 and cin <= 8 and cout > 4 else ()) + ((7,) if wout >= 32 else ()) + ((11,) if wout >= 16 and cout > 4 and cin % 8 == 0 else ())     # 7 = Winograd F(2x2,3x3); 11 = split-fp16 operands on the fp16 matrix pipe
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
@@ -127,6 +131,7 @@ def test_conv_fused_gn_silu_concat_temb_residual(cdx_mod, B, c0, c1, co, H, W, g
 @pytest.mark.parametrize("B,ci,c_a,c_b,H,W,k,s,tile", [(2, 32, 64, 32, 32, 32, 3, 1, -1), (1, 64, 128, 0, 16, 16, 3, 1, -1), (2, 32, 96, 64, 8, 8, 1, 1, -1),
                                                         (2, 32, 64, 0, 40, 24, 3, 2, -1), (3, 32, 32, 32, 4, 4, 3, 1, -1), (1, 32, 160, 0, 64, 64, 3, 1, -1),
                                                         (2, 32, 160, 128, 40, 72, 3, 1, -1), (3, 64, 128, 0, 8, 32, 3, 1, -1),     # Winograd kernel, ragged tiles
+                                                        (2, 32, 192, 64, 40, 72, 3, 1, -1), (1, 64, 320, 0, 32, 32, 1, 1, -1),     # 128 + 64 channels: two sum slots per tile
                                                         (1, 32, 4, 0, 34, 42, 3, 1, -1)])       # cout = 4 WITH sums: not the small kernels (found by tools/fuzz_conv.py)
 @pytest.mark.parametrize("split", [True, False], ids=["split", "f32mfma"])
 def test_conv_epilogue_stats_match_standalone_gn(cdx_mod, B, ci, c_a, c_b, H, W, k, s, tile, split):
