@@ -1,0 +1,148 @@
+// SPLIT mode of the 16-bit convolution kernel (conv16_kernel.h): float32 convolution on the fp16 matrix pipe with hi | lo split
+// operands, reached through cdx_conv_f32 (conv.hip selects it as CDX_TILE_SPLIT).  Host packer + launch.
+// (A translation unit of its own: the kernel template is instantiated ~50 times here and in conv16.hip.)
+#include <math.h>
+#include <string.h>
+
+#include "conv16_kernel.h"
+
+using namespace cdx;
+
+namespace {
+inline int chunks_of(int c) { return (c + 31) / 32; }
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// SPLIT mode (conv16_kernel.h): float32 convolution on the fp16 matrix pipe, reached through cdx_conv_f32 (conv.hip).
+// Host: fp16 hi/lo fragment image of the weights, pre-scaled by 2^s with s chosen per layer so that max |w| 2^s lies in
+// [2^13, 2^14): hi = fp16(w 2^s), lo = fp16(w 2^s - hi) are then normal numbers for every weight above 2^-27 of the
+// largest.  Layout [ntile][chunk][tap][j = 0..1][plane = hi, lo][lane][8 halves], + 16 KiB zero pad.
+extern "C" size_t cdx_conv_split_packed_halves(int32_t c0, int32_t c1, int32_t cout, int32_t ksize) {
+    if (c0 <= 0 || c1 < 0 || cout <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    const size_t ntiles = (cout + 31) / 32, nch = chunks_of(c0) + chunks_of(c1);
+    return ntiles * nch * ksize * ksize * 2048 + 8192;
+}
+
+extern "C" int cdx_conv_pack_weights_split_f16(const float* w, int32_t c0, int32_t c1, int32_t cout, int32_t ksize,
+                                               cdx_half* packed, float* unscale) {
+    CDX_REQUIRE(w && packed && unscale && c0 > 0 && c1 >= 0 && cout > 0 && (ksize == 1 || ksize == 3));
+    const int taps = ksize * ksize, ctot = c0 + c1;
+    const int nch0 = chunks_of(c0), nch = nch0 + chunks_of(c1), ntiles = (cout + 31) / 32;
+    float wmax = 0.f;
+    for (size_t i = 0; i < (size_t)cout * ctot * taps; ++i) {
+        CDX_REQUIRE(w[i] == w[i] && w[i] - w[i] == 0.f);      // finite
+        wmax = fmaxf(wmax, fabsf(w[i]));
+    }
+    int e = 0;
+    if (wmax > 0.f) {
+        frexpf(wmax, &e);                  // wmax = m 2^e, m in [0.5, 1)
+        e = 14 - e;                        // wmax 2^e in [2^13, 2^14)
+        if (e > 100) e = 100;
+        if (e < -100) e = -100;
+    }
+    const float sc = ldexpf(1.f, e);
+    *unscale = ldexpf(1.f, -e);
+    _Float16* o = reinterpret_cast<_Float16*>(packed);
+    for (int nt = 0; nt < ntiles; ++nt)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int j = 0; j < 2; ++j)
+                    for (int plane = 0; plane < 2; ++plane)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int k = 0; k < 8; ++k) {
+                                const int n = nt * 32 + (lane & 31);
+                                const int cl = (ch < nch0 ? ch : ch - nch0) * 32 + 16 * j + 8 * (lane >> 5) + k;
+                                const int csrc = ch < nch0 ? c0 : c1;
+                                float v = 0.f;
+                                if (n < cout && cl < csrc) v = w[((size_t)n * ctot + (ch < nch0 ? 0 : c0) + cl) * taps + tap] * sc;
+                                const _Float16 hi = (_Float16)v;
+                                *o++ = plane == 0 ? hi : (_Float16)(v - (float)hi);
+                            }
+    memset(o, 0, 8192 * sizeof(_Float16));
+    return CDX_OK;
+}
+
+namespace cdx {
+// Is this cdx_conv_f32 launch one the SPLIT kernel is built for?  (conv.hip asks before choosing the tile.)
+bool conv_split_ok(const cdx_conv_args* a) {
+    if (!a->wpacked_split || !aligned16(a->wpacked_split) || !(a->wsplit_unscale > 0.f)) return false;
+    // below 16 pixels wide the f32-MFMA split-K tiles stay: measured at 8^2 x 512 ch, batch 16, the 64-pixel split tile
+    // gives only 64 workgroups of 16 serial chunks each -- 1.12 ms per forward against 1.06 (3x3) and 0.17 against 0.15 (1x1)
+    if (a->wout < 16 || a->cout <= 4) return false;
+    if ((a->c0 % 8) != 0 || (a->c1 % 8) != 0) return false;                           // the loader moves 8-channel octets                                   // (8^2 and below: f32-MFMA split-K tiles)
+    if (a->stride == 2 && a->ksize != 3) return false;
+    if ((a->out_ld % 4) != 0 || a->out_ld < ((a->cout + 3) & ~3)) return false;      // outputs move as 4-channel vectors
+    if ((a->residual || a->stats_out) && (a->cout % 4) != 0) return false;
+    return true;
+}
+
+// GroupNorm-sum slots per spatial tile of a SPLIT launch: 2 when the 128-pixel tile's last channel block runs 2 x 2
+int conv_split_slots_per_tile(const cdx_conv_args* a) {
+    return conv16_tail_2x2(a->cout, (a->stride == 2 || a->wout < 32) ? 2 : 4) ? 2 : 1;
+}
+
+int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
+    Conv16Params p;
+    p.src[0] = a->src0;
+    p.src[1] = a->src1 ? a->src1 : a->src0;
+    p.csrc[0] = a->c0;
+    p.csrc[1] = a->c1 ? a->c1 : a->c0;
+    p.src_f32 = 1;
+    p.nchunk0 = chunks_of(a->c0);
+    p.nchunks = p.nchunk0 + chunks_of(a->c1);
+    p.ctot = a->c0 + a->c1;
+    p.B = a->batch; p.Hin = a->hin; p.Win = a->win; p.Hout = a->hout; p.Wout = a->wout; p.Cout = a->cout;
+    p.ups = (a->flags & CDX_CONV_UPSAMPLE2X) ? 1 : 0;
+    p.gn = (a->flags & CDX_CONV_GN) ? 1 : 0;
+    p.silu = (a->flags & CDX_CONV_SILU) ? 1 : 0;
+    p.abl = 0;
+    p.wunscale = a->wsplit_unscale;
+    p.w = a->wpacked_split;
+    p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift; p.temb = a->temb; p.temb_ld = a->temb_ld;
+    p.residual = a->residual;
+    p.out = a->out; p.out_f32 = 1; p.out_ld = a->out_ld; p.stats = a->stats_out;
+    p.stats_wm = conv_split_slots_per_tile(a);
+    // tile: 128 pixels x 128 channels at >= 32 pixels wide; 64 x 128 below (16^2 / 8^2 levels: twice the workgroups -- at
+    // batch 16 a 128-pixel tile leaves half of the CUs idle there) and for stride 2
+    const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : 3, tw = 1 << logtw;
+    const int bm = (a->stride == 2 || a->wout < 32) ? 64 : 128, th = bm / tw;
+    p.tiles_x = ceil_div(a->wout, tw);
+    p.tiles_y = ceil_div(a->hout, th);
+    CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
+    if (a->stride == 2) {      // 64 output pixels x 128 channels, one halo image (DB = 0)
+        if (logtw == 5) return conv16_launch<Conv16Cfg<3, 2, 5, 2, 3, 0, 1, 0>>(p, stream);
+        return conv16_launch<Conv16Cfg<3, 2, 4, 2, 3, 0, 1, 0>>(p, stream);
+    }
+    if (logtw == 4) {
+        if (a->ksize == 3) return conv16_launch<Conv16Cfg<3, 1, 4, 2, 3, 0, 1>>(p, stream);
+        return conv16_launch<Conv16Cfg<1, 1, 4, 2, 3, 0, 1>>(p, stream);
+    }
+    if (logtw == 3) {
+        if (a->ksize == 3) return conv16_launch<Conv16Cfg<3, 1, 3, 2, 3, 0, 1>>(p, stream);
+        return conv16_launch<Conv16Cfg<1, 1, 3, 2, 3, 0, 1>>(p, stream);
+    }
+#ifdef CDX_TUNING
+    if (a->ksize == 3 && variant) {      // timing ablations / tuning variants (tools/conv_bench.py --tiles 60..)
+        switch (variant) {
+            case 1: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 1, 1>>(p, stream);      // no epilogue
+            case 2: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 2, 1>>(p, stream);      // stage first chunk only
+            case 3: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 3, 1>>(p, stream);
+            case 4: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 4, 1>>(p, stream);      // no weight refills
+            case 7: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 7, 1>>(p, stream);
+            case 8: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 8, 1>>(p, stream);      // no LDS operand reads
+            case 15: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 15, 1>>(p, stream);    // MFMA stream only
+            case 20: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 16, 1>>(p, stream);    // no residual loads
+            case 21: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 32, 1>>(p, stream);    // no GroupNorm sums
+            case 22: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 48, 1>>(p, stream);    // neither
+            case 23: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 64, 1>>(p, stream);    // halo loads of chunks 0, 1 only
+            case 24: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 68, 1>>(p, stream);    // + no weight refills
+            case 16: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 6, 0, 1>>(p, stream);     // ring depth 6
+            case 17: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 2, 0, 1>>(p, stream);     // ring depth 2
+            default: return CDX_ENOTSUP;
+        }
+    }
+#endif
+    if (a->ksize == 3) return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 1>>(p, stream);
+    return conv16_launch<Conv16Cfg<1, 1, 5, 4, 3, 0, 1>>(p, stream);
+}
+}  // namespace cdx
