@@ -208,13 +208,17 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
 
     // Staging is cut into UNITS of half a pass (one pixel slot x 4 channels per thread: ~45 VALU instructions), so that a
     // unit rides on ONE 12-MFMA group without exceeding the issue slots the fp16 MFMA leaves free (a whole pass between two
-    // MFMAs was a 128-instruction clump behind an exec-mask branch).  unit u = (pass u >> 1, channel half u & 1).
-    h4 uo, uol;                                   // the unit being computed (hi | lo)
+    // MFMAs was a 128-instruction clump behind an exec-mask branch).  unit u = (pass u / UPP, channel group u % UPP).
+    // UPP units per pass: 2 (4 channels each) in SPLIT mode, whose groups hold 12 MFMAs; 4 (2 channels each) in the 16-bit
+    // storage modes, whose groups hold only MT = 4 MFMAs (a 4-channel unit there is ~10 VALU per MFMA: over the budget).
+    constexpr int UPP = (!C::SPLIT && 4 * NPASS + 1 <= GPC) ? 4 : 2, EPU = 8 / UPP;
+    using hU = __attribute__((ext_vector_type(EPU))) H;
+    hU uo, uol;                                       // the unit being computed (hi | lo)
     auto unit_elem = [&](int u, int k) {              // channel k of unit u
-        const int i = u >> 1, h = u & 1;
+        const int i = u / UPP, e = EPU * (u % UPP) + k;
         const bool ok = cvalid && ((vmask >> i) & 1u);
-        float v = pre[i][4 * h + k];
-        if constexpr (kGN) v = fmaf(v, gsc[h][k], gsh[h][k]);
+        float v = pre[i][e];
+        if constexpr (kGN) v = fmaf(v, gsc[e >> 2][e & 3], gsh[e >> 2][e & 3]);
         if constexpr (kSILU) v = silu16_f(v);
         if constexpr (C::SPLIT) {
             v = ok ? __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f) : 0.f;      // saturate instead of inf
@@ -223,25 +227,25 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         } else uo[k] = (H)(ok ? v : 0.f);
     };
     auto unit_store = [&](H* lds, int u) {
-        const int i = u >> 1, h = u & 1;
+        const int i = u / UPP, h = u % UPP;
         const int hp = i * 64 + pl;
         const int hy = hp / C::HW, hx = hp - hy * C::HW;
         // slots past the halo's last pixel (last pass only) dump into the 16 unused pad bytes of the thread's pass-0 pixel:
         // an unconditional store keeps the unit free of exec-mask branches (which pin its VALU work in one clump)
-        const int off = ((i + 1) * 64 <= C::NPIX || hp < C::NPIX) ? hy * RSH + hx * PSH + q * 8 + 4 * h
-                                                                   : (pl / C::HW) * RSH + (pl % C::HW) * PSH + KC * C::PLANES;
-        const int off_lo = ((i + 1) * 64 <= C::NPIX || hp < C::NPIX) ? off + KC : off + 4;
-        *reinterpret_cast<h4*>(&lds[off]) = uo;
-        if constexpr (C::SPLIT) *reinterpret_cast<h4*>(&lds[off_lo]) = uol;
+        const bool real = (i + 1) * 64 <= C::NPIX || hp < C::NPIX;
+        const int off = real ? hy * RSH + hx * PSH + q * 8 + EPU * h : (pl / C::HW) * RSH + (pl % C::HW) * PSH + KC * C::PLANES;
+        const int off_lo = real ? off + KC : off + 4;
+        *reinterpret_cast<hU*>(&lds[off]) = uo;
+        if constexpr (C::SPLIT) *reinterpret_cast<hU*>(&lds[off_lo]) = uol;
     };
     auto write_unit = [&](H* lds, int u) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) unit_elem(u, k);
+        for (int k = 0; k < EPU; ++k) unit_elem(u, k);
         unit_store(lds, u);
     };
     auto write_pass = [&](H* lds, int i) {
-        write_unit(lds, 2 * i);
-        write_unit(lds, 2 * i + 1);
+#pragma unroll
+        for (int h = 0; h < UPP; ++h) write_unit(lds, UPP * i + h);
     };
 
     // ---- MFMA operand addressing ----
@@ -308,7 +312,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     const int cq = ntile * 32 + (li & ~3);                    // first of this quad's 4 channels
     const bool quad_ok = nvalid && cq < p.Cout;               // (cout is a multiple of 4 or the tail is zero-weighted)
     // staging schedule inside a chunk: passes at groups G0 .. G0+NPASS-1, the loads of the chunk after next right behind
-    constexpr int NU = 2 * NPASS;
+    constexpr int NU = UPP * NPASS;
     constexpr int G0 = GPC > NU + 1 ? GPC - NU - 1 : 0;
     static_assert(NU + 1 <= GPC || GPC <= 2 || !C::DB, "staging units must fit in the chunk's groups (1x1: done after the groups)");
     issue_loads(0);
@@ -382,7 +386,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                     for (int k = 0; k < 4; ++k) {
 #pragma unroll
                         for (int m = k * NM / 4; m < (k + 1) * NM / 4; ++m) mfma_at(m);      // (NM = 6: quarters of 1, 2, 1, 2)
-                        unit_elem(g - G0, k);
+                        if (k < EPU) unit_elem(g - G0, k);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     unit_store(nxt, g - G0);
