@@ -90,6 +90,11 @@ class ExportImageArgs(C.Structure):
                 ("lo", C.c_float), ("hi", C.c_float), ("out", _f)]
 
 
+class RansDecodeArgs(C.Structure):
+    _fields_ = [("words", _f), ("stream_off", _f), ("stream_len", _f), ("freq", _f), ("nstreams", _i), ("nsym", _i),
+                ("alphabet", _i), ("prob_bits", _i), ("qmax", _i), ("step", C.c_float), ("out", _f), ("symbols", _f), ("status", _f)]
+
+
 class TileBlendArgs(C.Structure):
     _fields_ = [("tiles", _f), ("batch", _i), ("channels", _i), ("tile", _i), ("ny", _i), ("nx", _i),
                 ("y0", _f), ("x0", _f), ("h", _i), ("w", _i), ("out", _f)]
@@ -111,6 +116,7 @@ OPS = {
     "cond_embed_f32": CondEmbedArgs,
     "export_image_f32": ExportImageArgs,
     "tile_blend_f32": TileBlendArgs,
+    "rans_decode_i16": RansDecodeArgs,
 }
 
 # every exported symbol include/cdx.h declares (checked by tests/test_abi.py without a GPU)

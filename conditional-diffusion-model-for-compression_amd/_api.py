@@ -19,3 +19,7 @@ from . import context
 from .context import ContextNet, context_config, init_context_params, synthetic_latent, decode_latent
 
 __all__ += ["context", "ContextNet", "context_config", "init_context_params", "synthetic_latent", "decode_latent"]
+from . import bitstream
+from .bitstream import LatentDecoder, parse_latent_stream, decode_bitstreams
+
+__all__ += ["bitstream", "LatentDecoder", "parse_latent_stream", "decode_bitstreams"]

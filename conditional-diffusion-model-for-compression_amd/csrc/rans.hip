@@ -1,0 +1,81 @@
+// (f4) Bitstream side, first step: entropy decode of the quantised latent.
+// Static-model rANS (Duda 2013; 32-bit state, 16-bit renormalisation -- the "rans_word" form), one stream per
+// (image, latent channel), symbols = quantised latent values in [-qmax, qmax] against ONE frequency table per container
+// (build-defined format "CDXL": the reference snapshot holds no bitstream format -- README.md is 0 bytes; layout documented
+// in include/cdx.h and conditional-diffusion-model-for-compression_amd/bitstream.py).
+//
+//   decode step:  slot = x & (M - 1);  s = symbol whose [cum_s, cum_s + f_s) holds slot;
+//                 x = f_s (x >> prob_bits) + slot - cum_s;  if (x < 2^16) x = (x << 16) | next word
+//
+// Integer / byte work, latency-bound by the serial state update of each stream (a 256^2 image has 16 x 256 symbols), so
+// the mapping is simply lane = stream: 64 streams per wave walk their symbols in lockstep, the slot -> symbol table and
+// the cumulative frequencies sit in LDS (built once per workgroup), words are gathered per lane, and the dequantised
+// values are written symbol-major.  Malformed input never reads out of bounds: a stream that runs past its length or
+// does not end in the encoder's initial state sets *status instead.
+#include "common.h"
+
+using namespace cdx;
+
+namespace {
+
+constexpr int kMaxProbBits = 12;
+constexpr uint32_t kRansL = 1u << 16;
+
+__global__ __launch_bounds__(256) void rans_decode_kernel(const uint16_t* __restrict__ words, const uint32_t* __restrict__ off,
+                                                          const uint32_t* __restrict__ len, const uint16_t* __restrict__ freq,
+                                                          int nstreams, int nsym, int alphabet, int prob_bits, int qmax, float step,
+                                                          float* __restrict__ out, int16_t* __restrict__ symbols, int32_t* __restrict__ status) {
+    __shared__ uint16_t cum[1 << kMaxProbBits];          // cum[s] = sum of freq[0..s)   (alphabet <= 4096 entries used)
+    __shared__ uint16_t fr[1 << kMaxProbBits];
+    __shared__ uint16_t slot2sym[1 << kMaxProbBits];
+    const int tid = threadIdx.x;
+    const uint32_t M = 1u << prob_bits;
+    if (tid == 0) {                                      // alphabet is small (2 qmax + 1): a serial prefix sum
+        uint32_t c = 0;
+        for (int s = 0; s < alphabet; ++s) {
+            cum[s] = (uint16_t)c;
+            fr[s] = freq[s];
+            c += freq[s];
+        }
+    }
+    __syncthreads();
+    for (int s = tid; s < alphabet; s += blockDim.x)
+        for (uint32_t k = cum[s], e = min((uint32_t)cum[s] + fr[s], M); k < e; ++k) slot2sym[k] = (uint16_t)s;
+    __syncthreads();
+
+    const int st = blockIdx.x * blockDim.x + tid;
+    if (st >= nstreams) return;
+    const uint16_t* w = words + off[st];
+    const uint32_t n = len[st];
+    bool bad = n < 2;
+    uint32_t x = bad ? kRansL : ((uint32_t)w[0] << 16) | w[1];
+    uint32_t pos = 2;
+    for (int i = 0; i < nsym; ++i) {
+        const uint32_t slot = x & (M - 1);
+        const uint32_t s = slot2sym[slot];
+        x = (uint32_t)fr[s] * (x >> prob_bits) + slot - cum[s];
+        if (x < kRansL) {
+            if (pos < n) x = (x << 16) | w[pos++];
+            else bad = true;
+        }
+        const int q = (int)s - qmax;
+        out[(size_t)st * nsym + i] = (float)q * step;
+        if (symbols) symbols[(size_t)st * nsym + i] = (int16_t)q;
+    }
+    if (x != kRansL || pos != n) bad = true;             // the encoder starts from state 2^16 and every word must be consumed
+    if (bad && status) atomicOr(status, 1);
+}
+
+}  // namespace
+
+extern "C" size_t cdx_rans_decode_i16_workspace(const cdx_rans_decode_args*) { return 0; }
+extern "C" int cdx_rans_decode_i16(const cdx_rans_decode_args* a, void*, size_t, cdx_stream_t stream) {
+    CDX_REQUIRE(a && a->words && a->stream_off && a->stream_len && a->freq && a->out);
+    CDX_REQUIRE(a->nstreams > 0 && a->nsym > 0 && a->qmax >= 0 && a->alphabet == 2 * a->qmax + 1);
+    CDX_REQUIRE(a->prob_bits >= 1 && a->prob_bits <= kMaxProbBits && a->alphabet <= (1 << a->prob_bits));
+    CDX_REQUIRE((int64_t)a->nstreams * a->nsym < (1ll << 31));
+    hipLaunchKernelGGL(rans_decode_kernel, dim3((a->nstreams + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       a->words, a->stream_off, a->stream_len, a->freq, a->nstreams, a->nsym, a->alphabet, a->prob_bits,
+                       a->qmax, a->step, a->out, a->symbols, a->status);
+    return check_launch();
+}

@@ -338,6 +338,33 @@ typedef struct cdx_tile_blend_args {
 int cdx_tile_blend_f32(const cdx_tile_blend_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
 size_t cdx_tile_blend_f32_workspace(const cdx_tile_blend_args* a);
 
+/* ------------------------------------------------------------------------------------------
+ * (f4) Bitstream side: rANS decode of the quantised latent (format build-defined, "CDXL" v1).
+ * One stream per (image, latent channel); symbol s in [0, alphabet) stands for the latent value (s - qmax) * step;
+ * ONE static frequency table (sum = 2^prob_bits, every entry >= 1).  Stream layout (16-bit words): final encoder state
+ * (high word, low word), then the renormalisation words in DECODE order.  32-bit state, lower bound 2^16:
+ *   slot = x & (2^pb - 1); s: cum[s] <= slot < cum[s] + freq[s]; x = freq[s] (x >> pb) + slot - cum[s];
+ *   if (x < 2^16) x = (x << 16) | next word.
+ * out[stream][i] = dequantised value (float32), symbols (optional) = s - qmax as int16.  *status (optional, device,
+ * caller-zeroed) gets bit 0 set if any stream is malformed (runs past stream_len, or does not end in state 2^16 with
+ * every word consumed); reads never leave [stream_off, stream_off + stream_len).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cdx_rans_decode_args {
+    const uint16_t* words;      /* device: payload words of all streams */
+    const uint32_t* stream_off; /* device [nstreams]: first word of each stream */
+    const uint32_t* stream_len; /* device [nstreams]: words in each stream */
+    const uint16_t* freq;       /* device [alphabet] */
+    int32_t nstreams, nsym;     /* nsym symbols per stream (= latent h * w) */
+    int32_t alphabet, prob_bits, qmax; /* alphabet == 2 qmax + 1 <= 2^prob_bits, prob_bits <= 12 */
+    float step;                 /* dequantisation step */
+    float* out;                 /* device [nstreams, nsym] */
+    int16_t* symbols;           /* device [nstreams, nsym] or NULL */
+    int32_t* status;            /* device int32 or NULL */
+} cdx_rans_decode_args;
+
+int cdx_rans_decode_i16(const cdx_rans_decode_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_rans_decode_i16_workspace(const cdx_rans_decode_args* a);
+
 /* Diagnostics: monotonically counts kernel launches made through this library (relaxed atomic;
  * the only process-global the library keeps, used by tests to prove the HIP path ran). */
 uint64_t cdx_launch_count(void);

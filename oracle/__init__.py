@@ -17,7 +17,10 @@ from .sampler_ref import sample_ref, make_schedule_ref, step_coefficients_ref
 from .rng_ref import normal_ref, uniform_ref, stream_key_ref
 from .tiling_ref import sample_tiled_ref, blend_ref, origins_ref
 from .context_ref import context_forward_ref
+from .bitstream_ref import (quantise_ref, build_freq_ref, rans_encode_ref, rans_decode_ref, encode_latent_ref,
+                            decode_latent_ref)
 
 __all__ = ["unet_forward_ref", "timestep_embedding_ref", "sample_ref", "make_schedule_ref",
            "step_coefficients_ref", "normal_ref", "uniform_ref", "stream_key_ref",
-           "sample_tiled_ref", "blend_ref", "origins_ref", "context_forward_ref"]
+           "sample_tiled_ref", "blend_ref", "origins_ref", "context_forward_ref", "quantise_ref", "build_freq_ref", "rans_encode_ref", "rans_decode_ref",
+           "encode_latent_ref", "decode_latent_ref"]

@@ -55,6 +55,10 @@ def main():
     np.savez_compressed(os.path.join(HERE, "schedule.npz"), alphas_cumprod=np.array(ab),
                         ddim100=np.array(oracle.step_coefficients_ref(100, "ddim")),
                         ddpm250=np.array(oracle.step_coefficients_ref(250, "ddpm")))
+    # (f4) bitstream side: one small CDXL container from the oracle's rANS encoder + the symbols it encodes
+    q = oracle.quantise_ref(np.stack([oracle.normal_ref(oracle.stream_key_ref(9, c, 2), 20).reshape(4, 5) * (0.5 + c) for c in range(3)]), 0.25, 7)
+    np.savez_compressed(os.path.join(HERE, "latent_stream.npz"), container=np.frombuffer(oracle.encode_latent_ref(q, 0.25, 7), np.uint8),
+                        symbols=q.astype(np.int16), step=np.float32(0.25))
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
 
 
