@@ -4,7 +4,7 @@
 #include <math.h>
 #include <string.h>
 
-#include "conv16_kernel.h"
+#include "conv_kpar_kernel.h"
 
 using namespace cdx;
 
@@ -66,9 +66,9 @@ namespace cdx {
 // Is this cdx_conv_f32 launch one the SPLIT kernel is built for?  (conv.hip asks before choosing the tile.)
 bool conv_split_ok(const cdx_conv_args* a) {
     if (!a->wpacked_split || !aligned16(a->wpacked_split) || !(a->wsplit_unscale > 0.f)) return false;
-    // below 16 pixels wide the f32-MFMA split-K tiles stay: measured at 8^2 x 512 ch, batch 16, the 64-pixel split tile
-    // gives only 64 workgroups of 16 serial chunks each -- 1.12 ms per forward against 1.06 (3x3) and 0.17 against 0.15 (1x1)
-    if (a->wout < 16 || a->cout <= 4) return false;
+    // (below 8 pixels wide the f32-MFMA split-K tiles stay)
+    if (a->wout < 8 || a->cout <= 4) return false;
+    if (a->stride == 2 && a->wout < 16) return false;
     if ((a->c0 % 8) != 0 || (a->c1 % 8) != 0) return false;                           // the loader moves 8-channel octets                                   // (8^2 and below: f32-MFMA split-K tiles)
     if (a->stride == 2 && a->ksize != 3) return false;
     if ((a->out_ld % 4) != 0 || a->out_ld < ((a->cout + 3) & ~3)) return false;      // outputs move as 4-channel vectors
@@ -78,7 +78,8 @@ bool conv_split_ok(const cdx_conv_args* a) {
 
 // GroupNorm-sum slots per spatial tile of a SPLIT launch: 2 when the 128-pixel tile's last channel block runs 2 x 2
 int conv_split_slots_per_tile(const cdx_conv_args* a) {
-    return conv16_tail_2x2(a->cout, (a->stride == 2 || a->wout < 32) ? 2 : 4) ? 2 : 1;
+    if (a->stride == 1 && a->wout < 16) return 4;      // chunk-parallel tile (conv_kpar_kernel.h): one slot per finishing wave
+    return conv16_tail_2x2(a->cout, a->stride == 2 ? 2 : 4) ? 2 : 1;
 }
 
 int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
@@ -102,8 +103,9 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     p.residual = a->residual;
     p.out = a->out; p.out_f32 = 1; p.out_ld = a->out_ld; p.stats = a->stats_out;
     p.stats_wm = conv_split_slots_per_tile(a);
-    // tile: 128 pixels x 128 channels at >= 32 pixels wide; 64 x 128 below (16^2 / 8^2 levels: twice the workgroups -- at
-    // batch 16 a 128-pixel tile leaves half of the CUs idle there) and for stride 2
+    // tile: 128 pixels x 128 channels at >= 32 pixels wide; 64 x 128 for stride 2 and at 16 pixels wide; 64 pixels x 32
+    // channels with the input chunks split over the waves at 8 pixels wide (conv_kpar_kernel.h: at batch 16 that level has
+    // too few output pixels to fill 256 CUs with 128-channel tiles: 1.06 -> 0.49 ms per forward for its 3x3 layers)
     const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : 3, tw = 1 << logtw;
     const int bm = (a->stride == 2 || a->wout < 32) ? 64 : 128, th = bm / tw;
     p.tiles_x = ceil_div(a->wout, tw);
@@ -113,13 +115,14 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
         if (logtw == 5) return conv16_launch<Conv16Cfg<3, 2, 5, 2, 3, 0, 1, 0>>(p, stream);
         return conv16_launch<Conv16Cfg<3, 2, 4, 2, 3, 0, 1, 0>>(p, stream);
     }
-    if (logtw == 4) {
+    if (logtw == 4) {      // 16 pixels wide: 64 pixels x 128 channels (measured at 16^2 x 512, batch 16: 0.93 ms per forward for the
+        // 3x3 layers against 0.98 with the chunk-parallel tile, whose waves each stage a whole chunk for 32 channels)
         if (a->ksize == 3) return conv16_launch<Conv16Cfg<3, 1, 4, 2, 3, 0, 1>>(p, stream);
         return conv16_launch<Conv16Cfg<1, 1, 4, 2, 3, 0, 1>>(p, stream);
     }
-    if (logtw == 3) {
-        if (a->ksize == 3) return conv16_launch<Conv16Cfg<3, 1, 3, 2, 3, 0, 1>>(p, stream);
-        return conv16_launch<Conv16Cfg<1, 1, 3, 2, 3, 0, 1>>(p, stream);
+    if (logtw == 3) {      // 8 pixels wide: 64 pixels x 32 channels per workgroup, the 4 waves split the input chunks
+        if (a->ksize == 3) return conv_kpar_launch<KparCfg<3, 3>>(p, stream);
+        return conv_kpar_launch<KparCfg<1, 3>>(p, stream);
     }
 #ifdef CDX_TUNING
     if (a->ksize == 3 && variant) {      // timing ablations / tuning variants (tools/conv_bench.py --tiles 60..)

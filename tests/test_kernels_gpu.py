@@ -71,10 +71,10 @@ def tiles_for(k, s, wout=0, cout=999, cin=1024):
     """Every tile shape built for this ksize / stride (include/cdx.h CDX_TILE_*), plus -1 = the library's pick.
     Tile 7 = Winograd F(2x2,3x3) (3x3 stride 1, output width >= 32)."""
     if k == 1:
-        return (-1, 0, 1, 2) + ((5, 6) if wout < 32 else ()) + ((11,) if wout >= 16 and cout > 4 and cin % 8 == 0 else ())
+        return (-1, 0, 1, 2) + ((5, 6) if wout < 32 else ()) + ((11,) if wout >= 8 and cout > 4 and cin % 8 == 0 else ())
     if s == 2:
         return (-1, 3, 4, 5) + ((11,) if wout >= 16 and cout > 4 and cin % 8 == 0 else ())
-    return (-1, 0, 1, 2, 5, 6) + ((8, 9) if wout >= 32 and cout <= 4 else ()) + ((10,) if wout >= 32 and cin <= 8 and cout > 4 else ()) + ((7,) if wout >= 32 else ()) + ((11,) if wout >= 16 and cout > 4 and cin % 8 == 0 else ())     # 7 = Winograd F(2x2,3x3); 11 = split-fp16 operands on the fp16 matrix pipe
+    return (-1, 0, 1, 2, 5, 6) + ((8, 9) if wout >= 32 and cout <= 4 else ()) + ((10,) if wout >= 32 and cin <= 8 and cout > 4 else ()) + ((7,) if wout >= 32 else ()) + ((11,) if wout >= 8 and cout > 4 and cin % 8 == 0 else ())     # 7 = Winograd F(2x2,3x3); 11 = split-fp16 operands on the fp16 matrix pipe
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
