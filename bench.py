@@ -259,6 +259,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sample-call", action="store_true", help="skip the extra timing of one complete Sampler.sample()")
+    ap.add_argument("--dtype", default=None, choices=["fp32", "fp16", "bf16"], help="override the config's storage dtype (e.g. cfg2 in fp16 / bf16)")
     ap.add_argument("--no-split", action="store_true", help="A/B: float32 layers on the f32-input MFMA kernels only (no fp16 hi|lo split tile)")
     ap.add_argument("--details", action="store_true", help="print the per-variant conv table to stderr")
     args = ap.parse_args()
@@ -282,12 +283,14 @@ def main():
 
     # This rank's shard of the job: weak scaling, B units per GPU (cdx.shard owns the rank arithmetic).
     cfg, run = cdx.named_config(args.config)
+    if args.dtype:
+        cfg = cdx.unet_config(**dict(cfg, dtype=args.dtype))
     B = args.batch or {"cfg5": 16}.get(args.config, cdx.shard.IMAGES_PER_CALL[args.config])
     tiled = "image" in run
     tiles_per_image = len(cdx.tile_origins(run["image"], cfg["image_size"], run["overlap"])) ** 2 if tiled else 1
     images_per_gpu = 1 if tiled else B            # cfg5: the step loop runs B TILES; sample_call decodes one whole image
     job = cdx.shard.ShardJob(images_per_gpu * world, args.config, rank=rank, world=world, device=f"cuda:{local}",
-                             images_per_call=images_per_gpu, unet_kw={"split": False} if args.no_split else None)
+                             images_per_call=images_per_gpu, config=(cfg, run), unet_kw={"split": False} if args.no_split else None)
     sampler, net = job.sampler, job.sampler.unet
     sync = torch.cuda.synchronize
 
