@@ -1,5 +1,8 @@
-// fp16-storage convolution: implicit GEMM on v_mfma_f32_32x32x16_f16 (fp16 operands, fp32 accumulate).
-// BASELINE.json configs[4] ("fp16 UNet on CDNA4 MFMA"); SURVEY.md section 8(a) U3/U4 "_f16 variants".
+// 16-bit-operand convolution: implicit GEMM on v_mfma_f32_32x32x16_f16 / _bf16 (fp32 accumulate).  Three uses of ONE kernel:
+//   * fp16 storage  (BASELINE.json configs[4] "fp16 UNet on CDNA4 MFMA"; SURVEY.md section 8(a) U3/U4 "_f16 variants");
+//   * bf16 storage  (Conv16Cfg<..., BF = 1>);
+//   * FLOAT32 convolution with hi | lo split operands (SPLIT = 1, below): the dominant kernel of the float32 path.
+// No reference file exists to cite (the reference snapshot is empty); semantics = F.conv2d with the fusions of cdx.h.
 //
 // Same structure as conv_kernel.h -- a TH x TW pixel rectangle x 128 output channels per workgroup; per
 // 32-channel chunk the input halo is gathered to LDS once with GroupNorm scale/shift (fp32), SiLU, nearest-2x
@@ -12,8 +15,10 @@
 //     slots), row stride a multiple of 256 B;
 //   * sources may be fp32 (the sampler's x_t buffer feeding conv_in) or fp16; the output fp16 or fp32 (conv_out);
 //   * GroupNorm statistics are taken from the fp32 accumulators BEFORE rounding (GN stays fp32).
-// The kernel is no longer MFMA-bound (36.9k -> 2.3k MFMA cycles per chunk): the staging VALU, LDS reads and the
-// L2 weight stream set its speed.
+// In the 16-bit storage modes the kernel is not MFMA-bound (36.9k -> 2.3k MFMA cycles per chunk): the staging VALU, LDS
+// reads and the L2 weight stream set its speed.  Staging is cut into units interleaved with the MFMAs (below), halo loads
+// use buffer addressing, GroupNorm / SiLU modes are compile-time (STG), and the last channel block of a 128 + 64-channel
+// layer runs a 2 x 2 wave layout (WM).
 //
 // SPLIT = 1: the SAME kernel computes a FLOAT32 convolution on the fp16 matrix pipe (cdx_conv_f32's "split" tile).
 // Every float32 operand is split while staging into hi = fp16(v) and lo = fp16(v - hi) (v = hi + lo to ~2^-24 |v|; the

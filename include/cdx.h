@@ -45,7 +45,8 @@ int cdx_abi_version(void);
 const char* cdx_strerror(int status);
 
 /* ------------------------------------------------------------------------------------------
- * U3/U4/U5/U8/U9: convolution as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * U3/U4/U5/U8/U9: float32 convolution as implicit GEMM on the matrix pipe: v_mfma_f32_32x32x2_f32 (direct / Winograd
+ * tiles), or -- when wpacked_split is given -- three v_mfma_f32_32x32x16_f16 per product on hi | lo split operands.
  * Stands in for F.conv2d(silu(group_norm(cat[src0, src1]))) + bias + temb[:, :, None, None]
  * + residual, with nearest-2x upsampling and channel concat fused into the tile gather.
  * ------------------------------------------------------------------------------------------ */
