@@ -323,7 +323,7 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp16": "f16", "bf16": "bf16"}.get(cfg["dtype"], "f32"), "data": "synthetic",
         "arithmetic": ("%s storage, v_mfma_f32_32x32x16_%s, float32 accumulate" % (cfg["dtype"], "bf16" if cfg["dtype"] == "bf16" else "f16") if cfg["dtype"] != "fp32" else
-                       "float32 storage and results; layers >= 16 px wide: float32 products as 3 fp16 MFMAs on hi|lo split operands, "
+                       "float32 storage and results; layers >= 8 px wide: float32 products as 3 fp16 MFMAs on hi|lo split operands, "
                        "float32 accumulate (CDX_TILE_SPLIT); other layers: v_mfma_f32_32x32x2_f32" if not args.no_split else
                        "float32 storage, v_mfma_f32_32x32x2_f32 (direct + Winograd F(2x2,3x3))"),
         "config": {"workload": (f"BASELINE.json configs[1]: 256x256x3, 128-ch UNet (channel_mult 1,1,2,2,4,4; "

@@ -267,35 +267,39 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // SPLIT: bias + temb + residual enter through the accumulator init (scaled by 1/unscale, a power of two: exact), so the
+    // bias + temb + residual enter through the accumulator init (SPLIT: scaled by 1/unscale, a power of two: exact), so the
     // residual tile is fetched under the first chunk's staging instead of standing between the last MFMA and the stores
-    // (measured: the epilogue's residual loads were 6 % of the kernel).  Accumulator layout of the 32x32 MFMA: lane = channel
-    // n, register r of tile t = pixel m = 32 t + 8 (r >> 2) + 4 (lane >> 5) + (r & 3): one dword per lane, 128 B per half wave.
-    if constexpr (C::SPLIT) {
-        static_assert(C::LOGTW >= 3, "accumulator-init addressing assumes 8-pixel runs inside a tile row");
+    // (measured: the epilogue's residual loads were 6 % of the SPLIT kernel).  Accumulator layout of the 32x32 MFMA: lane =
+    // channel n, register r of tile t = pixel m = 32 t + 8 (r >> 2) + 4 (lane >> 5) + (r & 3): one element per lane (float32
+    // in SPLIT mode, the 16-bit storage type otherwise), 128 / 64 B per half wave.  (Tiles 4 pixels wide keep the epilogue
+    // form: there 4 (lane >> 5) crosses tile rows.)
+    constexpr bool kAccInit = C::SPLIT || C::LOGTW >= 3;
+    if constexpr (kAccInit) {
         const int n = ntile * 32 + li;
         if (nvalid && n < p.Cout) {
-            const float inv = 1.0f / p.wunscale;
+            const float inv = C::SPLIT ? 1.0f / p.wunscale : 1.0f;
             float add = p.bias ? p.bias[n] : 0.f;
             if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
             add *= inv;
             if (p.residual && !(C::ABL & 16)) {
                 // rows past the image end / columns past the row end read other (or no: bounded resource) pixels; those
                 // accumulators are never stored
+                constexpr unsigned es = C::SPLIT ? 4u : 2u;
                 const size_t first = (((size_t)b * p.Hout + oy0w) * p.Wout + ox0) * p.Cout;
-                const size_t left = ((size_t)p.B * p.Hout * p.Wout * p.Cout - first) * 4;
-                const __amdgpu_buffer_rsrc_t rr = buf_rsrc(static_cast<const float*>(p.residual) + first,
+                const size_t left = ((size_t)p.B * p.Hout * p.Wout * p.Cout - first) * es;
+                const __amdgpu_buffer_rsrc_t rr = buf_rsrc(static_cast<const char*>(p.residual) + first * es,
                                                            left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)left);
-                const unsigned voff = ((unsigned)(4 * lh) * (unsigned)p.Cout + (unsigned)n) * 4u;
+                const unsigned voff = ((unsigned)(4 * lh) * (unsigned)p.Cout + (unsigned)n) * es;
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        constexpr int dummy = 0;
                         const int mb = t * 32 + 8 * (r >> 2) + (r & 3);
                         const unsigned pix = (unsigned)(mb >> C::LOGTW) * (unsigned)p.Wout + (unsigned)(mb & (C::TW - 1));
-                        acc[t][r] = fmaf(buf_load1(rr, voff, pix * (unsigned)p.Cout * 4u), inv, add);
-                        (void)dummy;
+                        float rv;
+                        if constexpr (C::SPLIT) rv = buf_load1(rr, voff, pix * (unsigned)p.Cout * es);
+                        else rv = (float)__builtin_bit_cast(H, __builtin_amdgcn_raw_buffer_load_b16(rr, voff, pix * (unsigned)p.Cout * es, 0));
+                        acc[t][r] = fmaf(rv, inv, add);
                     }
             } else {
 #pragma unroll
@@ -456,7 +460,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             for (int k = 0; k < 4; ++k) {
                 float x[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) x[c] = C::SPLIT ? acc[t][4 * k + c] * un : acc[t][4 * k + c] + add;
+                for (int c = 0; c < 4; ++c) x[c] = C::SPLIT ? acc[t][4 * k + c] * un : kAccInit ? acc[t][4 * k + c] : acc[t][4 * k + c] + add;
                 quad_transpose(x, q4);                        // now: pixel 8k + q4 (+4 lh) of tile t, channels cq..cq+3
                 const int m = t * 32 + 8 * k + q4 + 4 * lh;
                 const int oy = oy0w + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
@@ -488,6 +492,10 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     using F_ = std::false_type;
     if constexpr (C::SPLIT) {          // float32 in, float32 out; bias / temb / residual are already in the accumulators
         if (p.stats && !(C::ABL & 32)) epilogue(F_{}, T_{}, T_{}); else epilogue(F_{}, F_{}, T_{});
+    } else if constexpr (kAccInit) {   // 16-bit storage, bias / temb / residual already in the accumulators
+        if (p.out_f32) epilogue(F_{}, F_{}, T_{});
+        else if (p.stats) epilogue(F_{}, T_{}, F_{});
+        else epilogue(F_{}, F_{}, F_{});
     } else if (p.out_f32) {
         if (p.residual) epilogue(T_{}, F_{}, T_{}); else epilogue(F_{}, F_{}, T_{});
     } else if (p.residual) {

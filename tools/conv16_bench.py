@@ -3,6 +3,7 @@
 import argparse, ctypes, os, sys, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+os.environ["CDX_TUNE"] = "1"      # ablation variants live in libcdx_tune.so (make EXPERIMENTS=1)
 import cdx
 from cdx import ops, _abi
 ap = argparse.ArgumentParser()
