@@ -180,6 +180,35 @@ def test_winograd_repeatable_across_launch_sequences(cdx_mod):
             assert err <= 2e-5 * max(ref.abs().max().item(), 1.0), f"round {rnd_i} case {j}: max abs diff {err:.3e}"
 
 
+def test_split_tiles_repeatable_across_launch_sequences(cdx_mod):
+    """The same flake detector for the split-fp16 tiles (128 x 128, 64 x 128, stride 2 with one halo image, the 2 x 2 tail
+    layout, and the chunk-parallel 8-pixel tile whose waves rely on in-order LDS operations): many launches, shapes
+    interleaved, NaN-prefilled outputs, each compared with the independent f32-MFMA direct kernel; and bit-identical
+    results from launch to launch (fixed summation orders)."""
+    ops = cdx_mod.ops
+    cases = [(2, 64, 128, 32, 32, 1, False), (2, 96, 192, 40, 36, 1, False), (2, 256, 96, 16, 16, 1, False), (3, 512, 64, 8, 8, 1, False),
+             (2, 64, 128, 36, 34, 2, False), (2, 128, 64, 8, 8, 1, True), (2, 160, 72, 8, 8, 1, False)]
+    first = {}
+    for rnd_i in range(12):
+        for j, (B, ci, co, H, W, s, up) in enumerate(cases):
+            x = nhwc(rnd(B, ci, H, W, seed=1000 + j))
+            w = rnd(co, ci, 3, 3, seed=2000 + j, scale=1.0 / math.sqrt(ci * 9))
+            pc = ops.PackedConv(w.numpy(), rnd(co, seed=3).numpy(), ci)
+            ho, wo = ((H * 2, W * 2) if up else (H, W)) if s == 1 else ((H + 1) // 2, (W + 1) // 2)
+            kw = dict(residual=nhwc(rnd(B, co, ho, wo, seed=3000 + j)), temb=rnd(B, co, seed=4000 + j).cuda()) if (rnd_i + j) & 1 else {}
+            got = torch.full((B, ho, wo, co), float("nan"), device="cuda")
+            ops.conv(pc, x, stride=s, upsample=up, tile=11, out=got, **kw)
+            assert not torch.isnan(got).any(), f"round {rnd_i} case {j}: unwritten outputs"
+            key = (j, bool(kw))
+            if key not in first:
+                ref = ops.conv(pc, x, stride=s, upsample=up, tile=3 if s == 2 else 0, **kw)
+                err = (got - ref).abs().max().item()
+                assert err <= 6e-6 * max(ref.abs().max().item(), 1.0), f"case {j}: max abs diff {err:.3e}"
+                first[key] = got.clone()
+            else:
+                assert torch.equal(got, first[key]), f"round {rnd_i} case {j}: result changed between launches"
+
+
 def test_gn_no_silu_1x1(cdx_mod):
     """Attention's qkv projection: conv1x1(gn(x)), no activation."""
     ops = cdx_mod.ops
