@@ -44,6 +44,22 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 __device__ __forceinline__ f32x16 mfma_32x32x16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
+// Two float32 values -> packed 16-bit pair(s).  SPLIT: hi = RN(v) as fp16 pair (v_cvt_pk_f16_f32), lo = RN(v - hi) computed by the
+// mixed-precision FMA (-1.0 * hi[f16] + v[f32], rounded once to fp16: v_fma_mixlo/mixhi_f16) -- 3 instructions per pair
+// where "convert, convert back, subtract, convert" took 7: beside the fp16 MFMA the staging VALU work is the co-limiter
+// (SQ counters: ~3.7 vector instructions per MFMA and wave before this change).
+__device__ __forceinline__ unsigned pack_hi_f16(float v0, float v1) {
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(v0), "v"(v1));
+    return r;
+}
+__device__ __forceinline__ unsigned pack_lo_f16(unsigned hi2, float v0, float v1) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi2), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(hi2), "v"(v1));
+    return r;
+}
+
 struct Conv16Params {
     const void* src[2];
     int csrc[2];
@@ -73,7 +89,8 @@ __host__ __device__ inline bool conv16_tail_2x2(int cout, int mt) { const int re
 
 // ABL: timing-only ablations (wrong results; libcdx_tune.so only): 1 = no epilogue, 2 = stage only the first chunk,
 // 4 = no weight refills, 8 = no LDS operand reads (registers reused), 16 = no residual loads, 32 = no GroupNorm sums,
-// 64 = halo global loads only for chunks 0 and 1 (later chunks restage stale registers: VALU + LDS-write cost stays)
+// 64 = halo global loads only for chunks 0 and 1 (later chunks restage stale registers: VALU + LDS-write cost stays),
+// 128 = staging units not interleaved with the MFMA quarters, 256 = units computed but not stored to LDS
 // DB = 0: ONE halo image and two barriers per chunk (stride-2 SPLIT tiles, whose 5 x 65-pixel hi|lo image would
 // otherwise leave room for a single workgroup per CU).
 // BF = 1: bfloat16 storage and v_mfma_f32_32x32x16_bf16 (dtype "bf16"); never together with SPLIT (fp16 hi | lo).
@@ -217,19 +234,29 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     // UPP units per pass: 2 (4 channels each) in SPLIT mode, whose groups hold 12 MFMAs; 4 (2 channels each) in the 16-bit
     // storage modes, whose groups hold only MT = 4 MFMAs (a 4-channel unit there is ~10 VALU per MFMA: over the budget).
     constexpr int UPP = (!C::SPLIT && 4 * NPASS + 1 <= GPC) ? 4 : 2, EPU = 8 / UPP;
-    using hU = __attribute__((ext_vector_type(EPU))) H;
-    hU uo, uol;                                       // the unit being computed (hi | lo)
-    auto unit_elem = [&](int u, int k) {              // channel k of unit u
-        const int i = u / UPP, e = EPU * (u % UPP) + k;
+    static_assert(EPU % 2 == 0, "units are built from channel pairs");
+    unsigned uo[EPU / 2], uol[EPU / 2];               // the unit being computed: packed 16-bit pairs (hi | lo)
+    auto unit_pair = [&](int u, int kp) {             // channels 2 kp, 2 kp + 1 of unit u
+        const int i = u / UPP, e = EPU * (u % UPP) + 2 * kp;
         const bool ok = cvalid && ((vmask >> i) & 1u);
-        float v = pre[i][e];
-        if constexpr (kGN) v = fmaf(v, gsc[e >> 2][e & 3], gsh[e >> 2][e & 3]);
-        if constexpr (kSILU) v = silu16_f(v);
-        if constexpr (C::SPLIT) {
-            v = ok ? __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f) : 0.f;      // saturate instead of inf
-            uo[k] = (H)v;
-            uol[k] = (H)(v - (float)uo[k]);                             // exact difference, rounded once
-        } else uo[k] = (H)(ok ? v : 0.f);
+        // padding pixels / channels past the source are zero AFTER the activation: clamp bounds (0, 0) give that for free
+        // (one select per pair instead of one per value); real values saturate at the fp16 range instead of overflowing
+        const float bound = ok ? 65504.f : 0.f;
+        float v[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            v[k] = pre[i][e + k];
+            if constexpr (kGN) v[k] = fmaf(v[k], gsc[(e + k) >> 2][(e + k) & 3], gsh[(e + k) >> 2][(e + k) & 3]);
+            if constexpr (kSILU) v[k] = silu16_f(v[k]);
+            v[k] = __builtin_amdgcn_fmed3f(v[k], -bound, bound);
+        }
+        if constexpr (C::BF) {
+            using b2 = __attribute__((ext_vector_type(2))) __bf16;
+            uo[kp] = __builtin_bit_cast(unsigned, b2{(__bf16)v[0], (__bf16)v[1]});
+        } else {
+            uo[kp] = pack_hi_f16(v[0], v[1]);
+            if constexpr (C::SPLIT) uol[kp] = pack_lo_f16(uo[kp], v[0], v[1]);
+        }
     };
     auto unit_store = [&](H* lds, int u) {
         const int i = u / UPP, h = u % UPP;
@@ -240,12 +267,24 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         const bool real = (i + 1) * 64 <= C::NPIX || hp < C::NPIX;
         const int off = real ? hy * RSH + hx * PSH + q * 8 + EPU * h : (pl / C::HW) * RSH + (pl % C::HW) * PSH + KC * C::PLANES;
         const int off_lo = real ? off + KC : off + 4;
-        *reinterpret_cast<hU*>(&lds[off]) = uo;
-        if constexpr (C::SPLIT) *reinterpret_cast<hU*>(&lds[off_lo]) = uol;
+        using uU = __attribute__((ext_vector_type(EPU / 2))) unsigned;
+        uU w, wl;
+#pragma unroll
+        for (int k = 0; k < EPU / 2; ++k) {
+            if constexpr (EPU == 2) { w = uo[0]; wl = uol[0]; }
+            else { w[k] = uo[k]; wl[k] = uol[k]; }
+        }
+        if constexpr (C::ABL & 256) {      // ablation: units computed but not stored (keeps the values alive)
+            if (w[0] == 0x12345678u) *reinterpret_cast<uU*>(&lds[off]) = w;
+            if constexpr (C::SPLIT) if (wl[0] == 0x12345678u) *reinterpret_cast<uU*>(&lds[off_lo]) = wl;
+            return;
+        }
+        *reinterpret_cast<uU*>(&lds[off]) = w;
+        if constexpr (C::SPLIT) *reinterpret_cast<uU*>(&lds[off_lo]) = wl;
     };
     auto write_unit = [&](H* lds, int u) {
 #pragma unroll
-        for (int k = 0; k < EPU; ++k) unit_elem(u, k);
+        for (int k = 0; k < EPU / 2; ++k) unit_pair(u, k);
         unit_store(lds, u);
     };
     auto write_pass = [&](H* lds, int i) {
@@ -260,7 +299,11 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     const bool nvalid = ntile * 32 < p.Cout;
     // packed weights: [ntile][chunk][tap][j = 0..1][plane][lane][8 halves] -> one group = GH halves (1 KiB per plane)
     constexpr int GH = 512 * C::PLANES;
-    const H* __restrict__ wp = static_cast<const H*>(p.w) + ((size_t)(nvalid ? ntile : 0) * p.nchunks * TAPS) * (2 * GH) + lane * 8;
+    // (buffer addressing: scalar resource per N-tile + lane offset + SCALAR fragment offset -- the flat form cost two 64-bit
+    // VALU adds per group)
+    const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(static_cast<const H*>(p.w) + ((size_t)(nvalid ? ntile : 0) * p.nchunks * TAPS) * (2 * GH));
+    const unsigned wlane = lane * 16u;
+    auto wload = [&](unsigned half_off) { return __builtin_bit_cast(h8, buf_load4(wrs, wlane, half_off * 2u)); };
 
     f32x16 acc[MT];
 #pragma unroll
@@ -314,7 +357,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
 #pragma unroll
     for (int j = 0; j < PF; ++j)
 #pragma unroll
-        for (int pl_ = 0; pl_ < C::PLANES; ++pl_) ring[j][pl_] = *reinterpret_cast<const h8*>(wp + j * GH + pl_ * 512);
+        for (int pl_ = 0; pl_ < C::PLANES; ++pl_) ring[j][pl_] = wload(j * GH + pl_ * 512);
 
     // packed-epilogue layout (see below)
     const int q4 = li & 3;
@@ -350,7 +393,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             }
         }
         if (nvalid) {
-            const H* __restrict__ wc = wp + (size_t)chunk * (TAPS * 2 * GH);
+            const unsigned wc = (unsigned)chunk * (unsigned)(TAPS * 2 * GH);      // halves, scalar
 #pragma unroll
             for (int g = 0; g < GPC; ++g) {
                 // Staging groups (g in [G0, G0 + NU), next chunk exists): the unit's four channel computations are placed
@@ -382,7 +425,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                 if constexpr (!(C::ABL & 4)) {
 #pragma unroll
                     for (int pl_ = 0; pl_ < C::PLANES; ++pl_)      // wraps into the next chunk / tail pad
-                        ring[g % PF][pl_] = *reinterpret_cast<const h8*>(wc + (size_t)(g + PF) * GH + pl_ * 512);
+                        ring[g % PF][pl_] = wload(wc + (unsigned)((g + PF) * GH + pl_ * 512));
                 }
                 // MFMA m of the group: term m / MT (hi*hi, lo*hi, hi*lo; lo*lo <= 2^-22 of the product is dropped), tile m % MT
                 auto mfma_at = [&](int m) {
@@ -395,7 +438,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                     for (int k = 0; k < 4; ++k) {
 #pragma unroll
                         for (int m = k * NM / 4; m < (k + 1) * NM / 4; ++m) mfma_at(m);      // (NM = 6: quarters of 1, 2, 1, 2)
-                        if (k < EPU) unit_elem(g - G0, k);
+                        if ((k & 1) == 0 && k / 2 < EPU / 2) unit_pair(g - G0, k / 2);      // pairs ride on quarters 0 and 2
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     unit_store(nxt, g - G0);

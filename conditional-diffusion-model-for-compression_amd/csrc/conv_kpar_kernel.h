@@ -111,21 +111,27 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
         const int hp = i * 16 + pl;
         const int hy = hp / C::HW, hx = hp - hy * C::HW;
         const bool ok = cvalid && ((vmask >> i) & 1u);
-        h8 o, ol;
+        const float bound = ok ? 65504.f : 0.f;                    // clamp bounds (0, 0) zero the padding after the activation
+        using u4 = __attribute__((ext_vector_type(4))) unsigned;
+        u4 o, ol;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v = pre[i][e];
-            if constexpr (kGN) v = fmaf(v, gsc[e >> 2][e & 3], gsh[e >> 2][e & 3]);
-            if constexpr (kSILU) v = silu16_f(v);
-            v = ok ? __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f) : 0.f;
-            o[e] = (H)v;
-            ol[e] = (H)(v - (float)o[e]);
+        for (int e = 0; e < 8; e += 2) {
+            float v[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                v[k] = pre[i][e + k];
+                if constexpr (kGN) v[k] = fmaf(v[k], gsc[(e + k) >> 2][(e + k) & 3], gsh[(e + k) >> 2][(e + k) & 3]);
+                if constexpr (kSILU) v[k] = silu16_f(v[k]);
+                v[k] = __builtin_amdgcn_fmed3f(v[k], -bound, bound);
+            }
+            o[e / 2] = pack_hi_f16(v[0], v[1]);                    // hi pair, lo pair = RN(v - hi) by mixed-precision FMA
+            ol[e / 2] = pack_lo_f16(o[e / 2], v[0], v[1]);
         }
         // slots past the halo's last pixel dump into the pad bytes of the lane's pass-0 pixel (no exec-mask branch)
         const bool real = (i + 1) * 16 <= C::NPIX || hp < C::NPIX;
         const int off = real ? hy * RSH + hx * PSH + q * 8 : (pl / C::HW) * RSH + (pl % C::HW) * PSH + 2 * KC;
-        *reinterpret_cast<h8*>(&lds[off]) = o;
-        if (real) *reinterpret_cast<h8*>(&lds[off + KC]) = ol;
+        *reinterpret_cast<u4*>(&lds[off]) = o;
+        if (real) *reinterpret_cast<u4*>(&lds[off + KC]) = ol;
     };
 
     // ---- MFMA operand addressing ----

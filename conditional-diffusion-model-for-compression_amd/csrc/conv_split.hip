@@ -139,6 +139,9 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
             case 22: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 48, 1>>(p, stream);    // neither
             case 23: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 64, 1>>(p, stream);    // halo loads of chunks 0, 1 only
             case 24: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 68, 1>>(p, stream);    // + no weight refills
+            case 25: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 128, 1>>(p, stream);   // units not interleaved
+            case 26: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 256, 1>>(p, stream);   // units computed, not stored
+            case 27: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 320, 1>>(p, stream);   // ... and no halo loads after chunk 1
             case 16: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 6, 0, 1>>(p, stream);     // ring depth 6
             case 17: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 2, 0, 1>>(p, stream);     // ring depth 2
             default: return CDX_ENOTSUP;
