@@ -1,0 +1,40 @@
+"""bench.py's output contract on the GPU box: one JSON line with the keys the driver reads, `value` consistent with
+`ms_per_step`, a roofline object with frac <= 1, and the same through torch.distributed.run (world size 1: RCCL init,
+barrier and max-reduce path of the N > 1 launch).  Needs a GPU: run with -m gpu."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config"}
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("launcher", ["plain", "torchrun"])
+def test_bench_line_contract(lib, launcher):
+    args = ["bench.py", "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-sample-call"]
+    cmd = [sys.executable] + args if launcher == "plain" else \
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+         "--master-port", "29571"] + args
+    d = _run(cmd)
+    assert KEYS <= set(d), KEYS - set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["unit"] == "images/s" and d["scaling"] == "weak"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert "256x256" in d["metric"] and "workload" in d["config"] and "model" not in d["config"]
+    # value = images of the whole job / (100 steps x seconds per step)
+    assert abs(d["value"] - 16 / (100 * d["ms_per_step"] * 1e-3)) <= 2e-3 * d["value"]
+    roof = d["roofline"]
+    assert roof["bound"] in ("mfma", "hbm") and 0 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["traffic"] is None or roof["traffic"] > 0
