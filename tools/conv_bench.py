@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="16,256,256,128,0,128,3,1")
 ap.add_argument("--tiles", default="-1")
 ap.add_argument("--gn", action="store_true", help="fuse GroupNorm scale/shift + SiLU on load + temb + residual (ResBlock conv)")
+ap.add_argument("--check", action="store_true", help="compare every tile's output with the first tile's")
 ap.add_argument("--stats", action="store_true", help="also produce the GroupNorm partial sums of the output (as every normed layer of the UNet does)")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
@@ -37,12 +38,24 @@ if a.gn:
 args = ops.conv_args(pc, x0, x1, out, stride=s, **kw)
 if a.stats:
     _stats_keep = ops.conv_stats_buffer(args, "cuda")
+    _stats_big = torch.zeros(4 * _stats_keep.numel(), dtype=torch.float64, device="cuda")      # variants with more slots per tile
+    args.stats_out = _stats_big.data_ptr()
 flops = 2.0 * B * ho * wo * co * (c0 + c1) * k * k
 tiles = [int(t) for t in a.tiles.split(",")]
 L = _abi.lib()
 st = torch.cuda.current_stream().cuda_stream
 tiles = [t for t in tiles if L.cdx_conv_f32_tile(ctypes.byref(args), t, None, 0, st) == 0 or print(f"tile {t}: not built for this shape")]
 torch.cuda.synchronize()
+if a.check:
+    ref = None
+    for t in tiles:
+        out.zero_()
+        assert L.cdx_conv_f32_tile(ctypes.byref(args), t, None, 0, st) == 0
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = out.clone()
+        else:
+            print(f"tile {t}: max |diff| vs tile {tiles[0]} = {(out - ref).abs().max().item():.3e} (scale {ref.abs().max().item():.3f})")
 res = {t: [] for t in tiles}
 for r in range(a.rounds + 1):
     for t in tiles:
