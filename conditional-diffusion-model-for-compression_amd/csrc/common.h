@@ -84,6 +84,12 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
     asm volatile("s_nop 1" : "+v"(v));
 }
+// (one dword of data: no such hazard is documented, but the same tie costs one scalar slot and keeps the store's data
+// register out of reach of the next instruction all the same)
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+    asm volatile("s_nop 0" : "+v"(v));
+}
 
 }  // namespace cdx
 

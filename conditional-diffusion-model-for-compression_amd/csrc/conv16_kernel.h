@@ -472,19 +472,69 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     }
     const int n = ntile * 32 + li;
     const bool nok = n < p.Cout;
+    if constexpr (C::SPLIT) {
+        // float32 out, straight from the accumulator layout (lane = channel): one dword per lane and register, 128 B per half
+        // wave and pixel -- full cache lines, no cross-lane transposes, no per-store address arithmetic (scalar offset per
+        // register, lane offset fixed), GroupNorm sums per lane = per channel.  (The 4 x 4 quad-transposed form below cost
+        // ~43 vector instructions per 16-byte store, 8 of them quarter-rate integer multiplies for the flat address.)
+        constexpr int ROWS = (MT * 32) >> C::LOGTW;
+        const bool full = oy0w + ROWS <= p.Hout && ox0 + C::TW <= p.Wout;          // wave-uniform
+        const size_t first = (((size_t)b * p.Hout + oy0w) * p.Wout + ox0) * p.out_ld;
+        const size_t left = ((size_t)p.B * p.Hout * p.Wout * p.out_ld - first) * 4;
+        constexpr unsigned kDrop = 0x80000000u;                                    // beyond any resource: the store is dropped
+        const __amdgpu_buffer_rsrc_t ors = buf_rsrc(static_cast<float*>(p.out) + first, left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)left);
+        const unsigned vbase = nok ? ((unsigned)(4 * lh) * (unsigned)p.out_ld + (unsigned)n) * 4u : kDrop;
+        const float un = p.wunscale;
+        const bool want_stats = p.stats && !(C::ABL & 32);
+        double s1 = 0, s2 = 0;
+        auto direct = [&](auto full_, auto has_stats) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mb = t * 32 + 8 * (r >> 2) + (r & 3);
+                    const int row = mb >> C::LOGTW, col = mb & (C::TW - 1);
+                    const unsigned soff = ((unsigned)row * (unsigned)p.Wout + (unsigned)col) * (unsigned)p.out_ld * 4u;
+                    const float x = acc[t][r] * un;
+                    bool ok = true;
+                    if constexpr (!decltype(full_)::value) ok = oy0w + row < p.Hout && ox0 + col + 4 * lh < p.Wout;
+                    if constexpr (decltype(has_stats)::value) {
+                        const double d = ok ? (double)x : 0.0;
+                        s1 += d;
+                        s2 = fma(d, d, s2);
+                    }
+                    buf_store1(ors, ok ? vbase : kDrop, soff, x);       // (last use of x: the tie in buf_store1 then costs no copy)
+                }
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        if (full) { if (want_stats) direct(T_{}, T_{}); else direct(T_{}, F_{}); }
+        else      { if (want_stats) direct(F_{}, T_{}); else direct(F_{}, F_{}); }
+        if (want_stats) {
+            s1 += __shfl_xor(s1, 32);                  // the two lane halves hold different pixels of the same channel
+            s2 += __shfl_xor(s2, 32);
+            if (lh == 0 && nok) {
+                const int slot = (ty * p.tiles_x + tx) * p.stats_wm + (WM == 2 ? wm : 0);
+                const int nslots = p.tiles_y * p.tiles_x * p.stats_wm;
+                double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + n) * 2;
+                o[0] = s1;
+                o[1] = s2;
+            }
+        }
+        return;
+    }
     float add = 0.f;
     if (nok) {
         add = p.bias ? p.bias[n] : 0.f;
         if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
     }
-    // Packed epilogue: 4x4 blocks (4 consecutive pixels x the quad's 4 channels) are transposed across lane quads in
+    // 16-bit storage -- packed epilogue: 4x4 blocks (4 consecutive pixels x the quad's 4 channels) are transposed across lane quads in
     // registers, so every lane stores / loads 4 consecutive channels of ONE pixel (8 B fp16, 16 B fp32) -- 4x fewer,
     // 4x wider memory instructions than the accumulator layout allows.  GroupNorm sums are reduced in that layout.
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    const float un = p.wunscale;            // SPLIT: undo the weights' power-of-two scaling (exact); 1 otherwise
     auto epilogue = [&](auto has_res, auto has_stats, auto out32) __attribute__((always_inline)) {
-        using res_t = std::conditional_t<C::SPLIT != 0, f32x4, h4>;      // residual: float32 in SPLIT mode
-        using rel_t = std::conditional_t<C::SPLIT != 0, float, H>;
+        using res_t = h4;
+        using rel_t = H;
         res_t rv[MT][4];
         if constexpr (decltype(has_res)::value) {      // one batch of 8/16-byte loads (a load in the last chunk instead
 #pragma unroll                                          // would queue the weight ring behind HBM misses: vmcnt is in-order)
@@ -503,7 +553,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             for (int k = 0; k < 4; ++k) {
                 float x[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) x[c] = C::SPLIT ? acc[t][4 * k + c] * un : kAccInit ? acc[t][4 * k + c] : acc[t][4 * k + c] + add;
+                for (int c = 0; c < 4; ++c) x[c] = kAccInit ? acc[t][4 * k + c] : acc[t][4 * k + c] + add;
                 quad_transpose(x, q4);                        // now: pixel 8k + q4 (+4 lh) of tile t, channels cq..cq+3
                 const int m = t * 32 + 8 * k + q4 + 4 * lh;
                 const int oy = oy0w + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
@@ -533,9 +583,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    if constexpr (C::SPLIT) {          // float32 in, float32 out; bias / temb / residual are already in the accumulators
-        if (p.stats && !(C::ABL & 32)) epilogue(F_{}, T_{}, T_{}); else epilogue(F_{}, F_{}, T_{});
-    } else if constexpr (kAccInit) {   // 16-bit storage, bias / temb / residual already in the accumulators
+    if constexpr (kAccInit) {   // 16-bit storage, bias / temb / residual already in the accumulators
         if (p.out_f32) epilogue(F_{}, F_{}, T_{});
         else if (p.stats) epilogue(F_{}, T_{}, F_{});
         else epilogue(F_{}, F_{}, F_{});
