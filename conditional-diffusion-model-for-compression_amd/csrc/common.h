@@ -90,6 +90,10 @@ __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned vo
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
     asm volatile("s_nop 0" : "+v"(v));
 }
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, voff, soff, 0);
+    asm volatile("s_nop 0" : "+v"(v));
+}
 
 }  // namespace cdx
 

@@ -523,6 +523,71 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         }
         return;
     }
+    if constexpr (kAccInit) {
+        // 16-bit out from the accumulator layout: lanes (2c, 2c+1) exchange one value per register pair (r, r+1 = the next
+        // pixel of the row), so the even lane stores channels (2c, 2c+1) of pixel r and the odd lane those of pixel r+1 --
+        // one packed dword per lane, 64 B per pixel and half wave, scalar offset per pair, GroupNorm sums per lane = channel
+        // (from the float32 accumulators, before rounding).  5 vector instructions per pair + the sums, where the
+        // quad-transposed form below cost ~30 per 8-byte store.
+        if (!p.out_f32 && !(p.Cout & 1)) {
+            constexpr int ROWS = (MT * 32) >> C::LOGTW;
+            const bool full = oy0w + ROWS <= p.Hout && ox0 + C::TW <= p.Wout;      // wave-uniform
+            const size_t first = (((size_t)b * p.Hout + oy0w) * p.Wout + ox0) * p.out_ld;
+            const size_t left = ((size_t)p.B * p.Hout * p.Wout * p.out_ld - first) * 2;
+            constexpr unsigned kDrop = 0x80000000u;
+            const __amdgpu_buffer_rsrc_t ors = buf_rsrc(static_cast<H*>(p.out) + first, left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)left);
+            const int odd = li & 1;
+            const unsigned vbase = nok ? ((unsigned)(4 * lh + odd) * (unsigned)p.out_ld + (unsigned)(n - odd)) * 2u : kDrop;
+            const unsigned rot = odd ? 16u : 0u;
+            const bool want_stats = p.stats && !(C::ABL & 32);
+            double s1 = 0, s2 = 0;
+            auto direct = [&](auto full_, auto has_stats) __attribute__((always_inline)) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int mb = t * 32 + 8 * (r >> 2) + (r & 3);
+                        const int row = mb >> C::LOGTW, col = mb & (C::TW - 1);
+                        const unsigned soff = ((unsigned)row * (unsigned)p.Wout + (unsigned)col) * (unsigned)p.out_ld * 2u;
+                        const float x0 = acc[t][r], x1 = acc[t][r + 1];
+                        bool ok0 = true, ok1 = true;
+                        if constexpr (!decltype(full_)::value) {
+                            const bool rok = oy0w + row < p.Hout;
+                            ok0 = rok && ox0 + col + 4 * lh < p.Wout;
+                            ok1 = rok && ox0 + col + 4 * lh + 1 < p.Wout;
+                        }
+                        if constexpr (decltype(has_stats)::value) {
+                            const double d0 = ok0 ? (double)x0 : 0.0, d1 = ok1 ? (double)x1 : 0.0;
+                            s1 += d0;
+                            s2 = fma(d0, d0, s2);
+                            s1 += d1;
+                            s2 = fma(d1, d1, s2);
+                        }
+                        const float got = quad_xor1(odd ? x0 : x1);          // the neighbour lane's value for MY pixel
+                        const float keep = odd ? x1 : x0;
+                        using h2 = __attribute__((ext_vector_type(2))) H;
+                        const unsigned pk = __builtin_bit_cast(unsigned, h2{(H)keep, (H)got});      // even lane: (n, n+1)
+                        buf_store1(ors, (odd ? ok1 : ok0) ? vbase : kDrop, soff, __builtin_amdgcn_alignbit(pk, pk, rot));   // odd: (n-1, n)
+                    }
+            };
+            using T_ = std::true_type;
+            using F_ = std::false_type;
+            if (full) { if (want_stats) direct(T_{}, T_{}); else direct(T_{}, F_{}); }
+            else      { if (want_stats) direct(F_{}, T_{}); else direct(F_{}, F_{}); }
+            if (want_stats) {
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (lh == 0 && nok) {
+                    const int slot = (ty * p.tiles_x + tx) * p.stats_wm + (WM == 2 ? wm : 0);
+                    const int nslots = p.tiles_y * p.tiles_x * p.stats_wm;
+                    double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + n) * 2;
+                    o[0] = s1;
+                    o[1] = s2;
+                }
+            }
+            return;
+        }
+    }
     float add = 0.f;
     if (nok) {
         add = p.bias ? p.bias[n] : 0.f;

@@ -3,13 +3,15 @@
 import argparse, ctypes, os, sys, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-os.environ["CDX_TUNE"] = "1"      # ablation variants live in libcdx_tune.so (make EXPERIMENTS=1)
+if "--shipped" not in sys.argv:
+    os.environ["CDX_TUNE"] = "1"      # ablation variants live in libcdx_tune.so (make EXPERIMENTS=1)
 import cdx
 from cdx import ops, _abi
 ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="16,256,256,128,0,128,3,1")
 ap.add_argument("--abl", default="0,1,2,3,4,7")
 ap.add_argument("--plain", action="store_true")
+ap.add_argument("--shipped", action="store_true", help="time libcdx.so (abl 0 only) instead of the tuning build")
 ap.add_argument("--nores", action="store_true")
 ap.add_argument("--nostats", action="store_true")
 a = ap.parse_args()

@@ -1,0 +1,10 @@
+#!/bin/bash
+# fp16 storage A/B: shipped libcdx.so (built from HEAD) against libcdx_tune.so (working tree)
+cd /root/repo
+for sh in 16,256,256,128,0,128,3,1 16,128,128,256,0,256,3,1 16,256,256,256,128,128,3,1 16,256,256,256,0,128,1,1; do
+  for rep in 1 2; do
+    timeout -k 10 120 python tools/conv16_bench.py --shape $sh --abl 0 --shipped | grep -v amdgpu.ids | sed 's/^/old /' || exit 1
+    timeout -k 10 120 python tools/conv16_bench.py --shape $sh --abl 0 | grep -v amdgpu.ids | sed 's/^/new /' || exit 1
+  done
+done
+CDX_TUNE=1 timeout -k 10 900 python -m pytest tests/test_fp16_gpu.py tests/test_bf16_gpu.py -m gpu -x -q 2>&1 | tail -5
