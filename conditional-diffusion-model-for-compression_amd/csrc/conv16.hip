@@ -37,9 +37,13 @@ int validate(const cdx_conv_f16_args* a) {
     return CDX_OK;
 }
 
+// M-tiles per workgroup: 128 pixels at >= 32 pixels wide; 64 for stride 2 and at 16 / 8 pixels wide, where 128-pixel tiles
+// of a batch-16 level leave most of the 256 CUs without a workgroup (16^2: 32 tiles x cout / 128)
+int f16_mt(const cdx_conv_f16_args* a) { return (a->stride == 2 || (a->wout >= 8 && a->wout < 32)) ? 2 : 4; }
+
 void tile_grid(const cdx_conv_f16_args* a, int& logtw, int& tx, int& ty) {
     logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : a->wout >= 8 ? 3 : 2;
-    const int bm = a->stride == 2 ? 64 : 128, tw = 1 << logtw, th = bm / tw;
+    const int bm = 32 * f16_mt(a), tw = 1 << logtw, th = bm / tw;
     tx = ceil_div(a->wout, tw);
     ty = ceil_div(a->hout, th);
 }
@@ -63,8 +67,8 @@ int conv16_dispatch(int ks, int stride, int logtw, bool bf, const Conv16Params& 
 #endif
     if (bf) return conv16_dispatch_bf16(ks, stride, logtw, p, stream);      // conv16_bf16.hip
 #define C16(KS, ST, LT, MT) if (ks == KS && stride == ST && logtw == LT) return conv16_launch<Conv16Cfg<KS, ST, LT, MT>>(p, stream);
-    C16(3, 1, 2, 4) C16(3, 1, 3, 4) C16(3, 1, 4, 4) C16(3, 1, 5, 4)
-    C16(1, 1, 2, 4) C16(1, 1, 3, 4) C16(1, 1, 4, 4) C16(1, 1, 5, 4)
+    C16(3, 1, 2, 4) C16(3, 1, 3, 2) C16(3, 1, 4, 2) C16(3, 1, 5, 4)
+    C16(1, 1, 2, 4) C16(1, 1, 3, 2) C16(1, 1, 4, 2) C16(1, 1, 5, 4)
     C16(3, 2, 2, 2) C16(3, 2, 3, 2) C16(3, 2, 4, 2) C16(3, 2, 5, 2)
 #undef C16
     return CDX_ENOTSUP;
@@ -130,7 +134,7 @@ extern "C" int32_t cdx_conv_f16_stats_slots(const cdx_conv_f16_args* a) {
     if (validate(a)) return 0;
     int logtw, tx, ty;
     tile_grid(a, logtw, tx, ty);
-    return tx * ty * (conv16_tail_2x2(a->cout, a->stride == 2 ? 2 : 4) ? 2 : 1);
+    return tx * ty * (conv16_tail_2x2(a->cout, f16_mt(a)) ? 2 : 1);
 }
 
 extern "C" int cdx_conv_f16(const cdx_conv_f16_args* a, void*, size_t, cdx_stream_t stream) {
@@ -155,7 +159,7 @@ extern "C" int cdx_conv_f16(const cdx_conv_f16_args* a, void*, size_t, cdx_strea
     p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift; p.temb = a->temb; p.temb_ld = a->temb_ld;
     p.residual = a->residual;
     p.out = a->out; p.out_f32 = a->out_is_f32 ? 1 : 0; p.out_ld = a->out_ld; p.stats = a->stats_out;
-    p.stats_wm = conv16_tail_2x2(a->cout, a->stride == 2 ? 2 : 4) ? 2 : 1;
+    p.stats_wm = conv16_tail_2x2(a->cout, f16_mt(a)) ? 2 : 1;
     int logtw;
     tile_grid(a, logtw, p.tiles_x, p.tiles_y);
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));

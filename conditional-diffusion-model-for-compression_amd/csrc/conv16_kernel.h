@@ -90,7 +90,8 @@ __host__ __device__ inline bool conv16_tail_2x2(int cout, int mt) { const int re
 // ABL: timing-only ablations (wrong results; libcdx_tune.so only): 1 = no epilogue, 2 = stage only the first chunk,
 // 4 = no weight refills, 8 = no LDS operand reads (registers reused), 16 = no residual loads, 32 = no GroupNorm sums,
 // 64 = halo global loads only for chunks 0 and 1 (later chunks restage stale registers: VALU + LDS-write cost stays),
-// 128 = staging units not interleaved with the MFMA quarters, 256 = units computed but not stored to LDS
+// 128 = staging units not interleaved with the MFMA quarters, 256 = units computed but not stored to LDS,
+// 512 = per-wave phase stamps instead of GroupNorm sums (use with 32), 2048 = SiLU without its transcendentals
 // DB = 0: ONE halo image and two barriers per chunk (stride-2 SPLIT tiles, whose 5 x 65-pixel hi|lo image would
 // otherwise leave room for a single workgroup per CU).
 // BF = 1: bfloat16 storage and v_mfma_f32_32x32x16_bf16 (dtype "bf16"); never together with SPLIT (fp16 hi | lo).
@@ -152,6 +153,29 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
     const int oy0w = oy0 + ((wm * MT * 32) >> C::LOGTW);           // first output row of THIS wave's M-tiles
     const int iy0 = oy0 * C::STRIDE - C::PAD, ix0 = ox0 * C::STRIDE - C::PAD;
+    // ABL & 512 (diagnostic build): s_memtime stamps per wave at the phase boundaries, 16 per wave, into the buffer behind
+    // p.stats (which then holds no sums): 0 entry, 1 first loads issued, 2 first chunk staged (barrier passed), 3 + c chunk c
+    // done (c < 8), 12 stores issued, 13 HW_ID, 14 XCC_ID  (digest: tools/conv_bench.py --stamps)
+    auto stamp = [&](int k) __attribute__((always_inline)) {
+        if constexpr ((C::ABL & 512) != 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (lane == 0)
+                reinterpret_cast<unsigned long long*>(p.stats)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 16 + k] = t;
+        }
+    };
+    stamp(0);
+    if constexpr ((C::ABL & 512) != 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (lane == 0) {
+            reinterpret_cast<unsigned long long*>(p.stats)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 16 + 13] = hw;
+            reinterpret_cast<unsigned long long*>(p.stats)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 16 + 14] = xcc;
+        }
+    }
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
 
     // ---- loader: thread -> (pixel slot pl of 64, channel octet q of 4) ----
@@ -247,7 +271,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         for (int k = 0; k < 2; ++k) {
             v[k] = pre[i][e + k];
             if constexpr (kGN) v[k] = fmaf(v[k], gsc[(e + k) >> 2][(e + k) & 3], gsh[(e + k) >> 2][(e + k) & 3]);
-            if constexpr (kSILU) v[k] = silu16_f(v[k]);
+            if constexpr (kSILU) v[k] = (C::ABL & 2048) ? v[k] * (1.0f + v[k] * -1.44269504088896341f) * 0.5f : silu16_f(v[k]);
             v[k] = __builtin_amdgcn_fmed3f(v[k], -bound, bound);
         }
         if constexpr (C::BF) {
@@ -368,10 +392,12 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     constexpr int G0 = GPC > NU + 1 ? GPC - NU - 1 : 0;
     static_assert(NU + 1 <= GPC || GPC <= 2 || !C::DB, "staging units must fit in the chunk's groups (1x1: done after the groups)");
     issue_loads(0);
+    stamp(1);
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
     if (p.nchunks > 1 && !(C::ABL & 2)) issue_loads(1);
     __syncthreads();
+    stamp(2);
     h8 a[MT], al[MT];
     if constexpr (C::ABL & 8) {                 // ablation: operands read once
 #pragma unroll
@@ -449,6 +475,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             }
         }
         __syncthreads();
+        if (chunk < 8) stamp(3 + chunk);
         if constexpr (!C::DB) {      // single image: every wave is done reading it; write the next chunk in place
             if (more) {
 #pragma unroll
@@ -510,6 +537,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         using F_ = std::false_type;
         if (full) { if (want_stats) direct(T_{}, T_{}); else direct(T_{}, F_{}); }
         else      { if (want_stats) direct(F_{}, T_{}); else direct(F_{}, F_{}); }
+        stamp(12);
         if (want_stats) {
             s1 += __shfl_xor(s1, 32);                  // the two lane halves hold different pixels of the same channel
             s2 += __shfl_xor(s2, 32);
@@ -704,11 +732,17 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
 template <class C>
 inline int conv16_launch(const Conv16Params& p, hipStream_t stream) {
     dim3 grid(p.tiles_x * p.tiles_y * p.B, ceil_div(p.Cout, C::BN));
+    // (tuning build, abl 1024: unused dynamic LDS leaves room for ONE workgroup per CU -- the rate of a wave alone on its SIMD)
+    const unsigned dyn = (p.abl & 1024) ? 88u * 1024u : 0u;
+    auto go = [&](auto kern) {
+        if (dyn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipLaunchKernelGGL(kern, grid, dim3(256), dyn, stream, p);
+    };
     switch (p.gn ? (p.silu ? 2 : 1) : (p.silu ? 3 : 0)) {
-        case 0: hipLaunchKernelGGL((conv16_kernel<C, 0>), grid, dim3(256), 0, stream, p); break;
-        case 1: hipLaunchKernelGGL((conv16_kernel<C, 1>), grid, dim3(256), 0, stream, p); break;
-        case 2: hipLaunchKernelGGL((conv16_kernel<C, 2>), grid, dim3(256), 0, stream, p); break;
-        default: hipLaunchKernelGGL((conv16_kernel<C, 3>), grid, dim3(256), 0, stream, p); break;
+        case 0: go(conv16_kernel<C, 0>); break;
+        case 1: go(conv16_kernel<C, 1>); break;
+        case 2: go(conv16_kernel<C, 2>); break;
+        default: go(conv16_kernel<C, 3>); break;
     }
     return check_launch();
 }

@@ -126,7 +126,12 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     }
 #ifdef CDX_TUNING
     if (a->ksize == 3 && variant) {      // timing ablations / tuning variants (tools/conv_bench.py --tiles 60..)
+        if (variant >= 100) {            // + 100: the same variant (100 = the shipped tile) at ONE workgroup per CU (solo waves)
+            p.abl = 1024;
+            variant -= 100;
+        }
         switch (variant) {
+            case 0: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 1>>(p, stream);
             case 1: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 1, 1>>(p, stream);      // no epilogue
             case 2: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 2, 1>>(p, stream);      // stage first chunk only
             case 3: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 3, 1>>(p, stream);
@@ -139,6 +144,8 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
             case 22: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 48, 1>>(p, stream);    // neither
             case 23: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 64, 1>>(p, stream);    // halo loads of chunks 0, 1 only
             case 24: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 68, 1>>(p, stream);    // + no weight refills
+            case 33: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 2048, 1>>(p, stream);  // SiLU without exp / rcp (wrong results)
+            case 32: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 544, 1>>(p, stream);   // phase stamps into the stats buffer
             case 25: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 128, 1>>(p, stream);   // units not interleaved
             case 26: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 256, 1>>(p, stream);   // units computed, not stored
             case 27: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 320, 1>>(p, stream);   // ... and no halo loads after chunk 1

@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="16,256,256,128,0,128,3,1")
 ap.add_argument("--tiles", default="-1")
 ap.add_argument("--gn", action="store_true", help="fuse GroupNorm scale/shift + SiLU on load + temb + residual (ResBlock conv)")
+ap.add_argument("--stamps", type=int, default=0, help="tile id of a stamping variant (92): run it once and digest the per-wave phase stamps")
 ap.add_argument("--check", action="store_true", help="compare every tile's output with the first tile's")
 ap.add_argument("--stats", action="store_true", help="also produce the GroupNorm partial sums of the output (as every normed layer of the UNet does)")
 ap.add_argument("--rounds", type=int, default=5)
@@ -56,6 +57,56 @@ if a.check:
             ref = out.clone()
         else:
             print(f"tile {t}: max |diff| vs tile {tiles[0]} = {(out - ref).abs().max().item():.3e} (scale {ref.abs().max().item():.3f})")
+if a.stamps:
+    assert a.stats, "--stamps needs --stats (the stamps go to the stats buffer)"
+    for _ in range(3):
+        _stats_big.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        assert L.cdx_conv_f32_tile(ctypes.byref(args), a.stamps, None, 0, st) == 0
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    nw = B * ((ho + 3) // 4) * ((wo + 31) // 32) * ((co + 127) // 128) * 4
+    T = _stats_big.view(torch.int64)[: nw * 16].reshape(nw, 16).cpu().numpy().astype(np.int64)
+    np.save(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"stamps{a.stamps}.npy"), T)
+    xcc = T[:, 14] & 0xF
+    span = max(T[xcc == x][:, 12].max() - T[xcc == x][:, 0].min() for x in np.unique(xcc))     # (each XCD has its own counter base)
+    tick_ns = ms * 1e6 / span
+    nch = (c0 + c1 + 31) // 32
+    print(f"stamps: {nw} waves, launch {ms:.4f} ms (event), span {span} ticks -> {tick_ns:.2f} ns per tick")
+    life = (T[:, 12] - T[:, 0]) * tick_ns / 1e3
+    seg = {"entry->loads issued": T[:, 1] - T[:, 0], "loads issued->chunk0 staged+barrier": T[:, 2] - T[:, 1]}
+    for c in range(min(nch, 8)):
+        seg[f"chunk {c}"] = T[:, 3 + c] - T[:, 2 + c]
+    seg["epilogue (stores issued)"] = T[:, 12] - T[:, 2 + min(nch, 8)]
+    print(f"wave lifetime us: mean {life.mean():.2f}  p10 {np.percentile(life, 10):.2f}  p50 {np.percentile(life, 50):.2f}  p90 {np.percentile(life, 90):.2f}")
+    for k, v in seg.items():
+        v = v * tick_ns / 1e3
+        print(f"  {k:38s} mean {v.mean():7.3f} us  p10 {np.percentile(v, 10):7.3f}  p50 {np.percentile(v, 50):7.3f}  p90 {np.percentile(v, 90):7.3f}   share {v.mean() / life.mean():.3f}")
+    hw = T[:, 13]
+    simd_key = hw & 0xFFFFFFF0 & ~(0xF << 0)      # everything but the wave slot id (bits 3:0)
+    import collections
+    by = collections.defaultdict(list)
+    for i in range(nw):
+        by[(int(T[i, 14]) & 0xF, (int(hw[i]) >> 4) & 3, (int(hw[i]) >> 8) & 0xFF)].append((int(T[i, 0]), int(T[i, 12]), int(T[i, 2]), int(T[i, 2 + min(nch, 8)])))
+    conc, mf2, mf1, mf0, tot = [], 0, 0, 0, 0
+    for k, ws in by.items():
+        ev = []
+        for s0, s1, m0, m1 in ws:
+            ev += [(m0, 1), (m1, -1)]
+        ev.sort()
+        cur, last = 0, ev[0][0]
+        for t, d in ev:
+            dt = t - last
+            if cur >= 2: mf2 += dt
+            elif cur == 1: mf1 += dt
+            else: mf0 += dt
+            cur += d
+            last = t
+    tot = mf0 + mf1 + mf2
+    print(f"per SIMD (XCC, SE/SH/CU, SIMD): {len(by)} groups, {nw / len(by):.1f} waves each; time with >=2 / 1 / 0 waves inside their chunk loops: {mf2 / tot:.3f} / {mf1 / tot:.3f} / {mf0 / tot:.3f}")
+    sys.exit(0)
 res = {t: [] for t in tiles}
 for r in range(a.rounds + 1):
     for t in tiles:
