@@ -91,7 +91,7 @@ __host__ __device__ inline bool conv16_tail_2x2(int cout, int mt) { const int re
 // 4 = no weight refills, 8 = no LDS operand reads (registers reused), 16 = no residual loads, 32 = no GroupNorm sums,
 // 64 = halo global loads only for chunks 0 and 1 (later chunks restage stale registers: VALU + LDS-write cost stays),
 // 128 = staging units not interleaved with the MFMA quarters, 256 = units computed but not stored to LDS,
-// 512 = per-wave phase stamps instead of GroupNorm sums (use with 32), 2048 = SiLU without its transcendentals
+// 512 = per-wave phase stamps instead of GroupNorm sums (use with 32)
 // DB = 0: ONE halo image and two barriers per chunk (stride-2 SPLIT tiles, whose 5 x 65-pixel hi|lo image would
 // otherwise leave room for a single workgroup per CU).
 // BF = 1: bfloat16 storage and v_mfma_f32_32x32x16_bf16 (dtype "bf16"); never together with SPLIT (fp16 hi | lo).
@@ -271,7 +271,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         for (int k = 0; k < 2; ++k) {
             v[k] = pre[i][e + k];
             if constexpr (kGN) v[k] = fmaf(v[k], gsc[(e + k) >> 2][(e + k) & 3], gsh[(e + k) >> 2][(e + k) & 3]);
-            if constexpr (kSILU) v[k] = (C::ABL & 2048) ? v[k] * (1.0f + v[k] * -1.44269504088896341f) * 0.5f : silu16_f(v[k]);
+            if constexpr (kSILU) v[k] = silu16_f(v[k]);
             v[k] = __builtin_amdgcn_fmed3f(v[k], -bound, bound);
         }
         if constexpr (C::BF) {

@@ -144,7 +144,6 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
             case 22: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 48, 1>>(p, stream);    // neither
             case 23: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 64, 1>>(p, stream);    // halo loads of chunks 0, 1 only
             case 24: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 68, 1>>(p, stream);    // + no weight refills
-            case 33: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 2048, 1>>(p, stream);  // SiLU without exp / rcp (wrong results)
             case 32: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 544, 1>>(p, stream);   // phase stamps into the stats buffer
             case 25: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 128, 1>>(p, stream);   // units not interleaved
             case 26: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 256, 1>>(p, stream);   // units computed, not stored
