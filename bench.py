@@ -116,12 +116,12 @@ def kernel_model(variant) -> dict:
     if tile.startswith("f16"):
         return {"name": "conv16_kernel<Conv16Cfg> (v_mfma_f32_32x32x16_f16)", "executed_per_algorithmic": 1.0,
                 "peak": FP16_MFMA_PEAK_TFLOPS, "wino": False, "flops_per_mfma_cycle": 1024.0,
-                "pmc_pattern": "Conv16Cfg<%d, %d, %d, %d, 3, 0, 0, 1, " % (variant[0], variant[1], variant[2], 2 if variant[1] == 2 else 4)}
+                "pmc_pattern": "Conv16Cfg<%d, %d, %d, %d, 3, 0, 0, 1, " % (variant[0], variant[1], variant[2], 2 if (variant[1] == 2 or variant[2] in (3, 4)) else 4)}
     return {"name": "conv_kernel<ConvCfg> (direct implicit GEMM on v_mfma_f32_32x32x2_f32)", "executed_per_algorithmic": 1.0,
             "peak": FP32_MFMA_PEAK_TFLOPS, "wino": False, "flops_per_mfma_cycle": 64.0, "pmc_pattern": "conv_kernel<cdx::ConvCfg<%d, %d, %d, " % variant[:3]}
 
 
-def measure_dominant_kernel(plan, torch, reps=3):
+def measure_dominant_kernel(plan, torch, reps=3, workload="cfg2"):
     """Per-launch HIP-event timing of every conv launch of one forward; returns the roofline object for the
     kernel symbol with the most FLOPs, plus a per-variant table."""
     import ctypes
@@ -185,7 +185,9 @@ def measure_dominant_kernel(plan, torch, reps=3):
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
             continue
-        same_kernel = tr.get("pattern") == km["pmc_pattern"]
+        # (a digest is an average over the launches of ONE workload's command: another config's launches of the same kernel
+        # symbol have other shapes -- digests without a "config" field predate the check and were taken on cfg2)
+        same_kernel = tr.get("pattern") == km["pmc_pattern"] and tr.get("config", "cfg2") == workload
         if same_kernel and tr.get("csrc_sha16") == sha:
             roof["traffic"] = round(tr["hbm_bytes_per_launch"])
             roof["traffic_over_algorithmic"] = round(tr["hbm_bytes_per_launch"] / roof["algorithmic_bytes_per_launch"], 3)
@@ -351,7 +353,7 @@ def main():
                                "ms_per_step_equiv": round(sec * 1e3 / (run["steps"] * (-(-tiles_per_image // B) if tiled else 1)), 3)}
         assert all(torch.isfinite(v).all() for v in out.values())
     if rank == 0 and not args.no_roofline:
-        roof, table = measure_dominant_kernel(plan, torch)
+        roof, table = measure_dominant_kernel(plan, torch, workload=args.config)
         line["roofline"] = roof
         if args.details:
             print(json.dumps({"conv_variants": table, "flops": fl}, indent=1), file=sys.stderr)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Digest rocprofv3 --pmc passes into the tracked JSON files under profiles/.
 
-  tools/pmc_digest.py traffic <dir of FETCH_SIZE pass> <dir of WRITE_SIZE pass> <kernel substring> [out.json]
+  tools/pmc_digest.py traffic <dir of FETCH_SIZE pass> <dir of WRITE_SIZE pass> <kernel substring> [out.json [config]]
   tools/pmc_digest.py mfma    <dir of SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE pass> <kernel substring> <mfma-cycles-per-launch> [out.json]
 
 traffic -- per launch of the named kernel: HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section: on
@@ -44,6 +44,7 @@ def sha():
 def traffic(argv):
     fdir, wdir, pat = argv[:3]
     out = argv[3] if len(argv) > 3 else None
+    config = argv[4] if len(argv) > 4 else "cfg2"          # the bench.py --config the passes ran (bench.py checks it)
     fetch, write = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
     f = [v for k, v in fetch if pat in k]
     w = [v for k, v in write if pat in k]
@@ -53,9 +54,11 @@ def traffic(argv):
     res = {
         "kernel": name.split("(")[0],
         "pattern": pat,
+        "config": config,
         "csrc_sha16": sha(),
         "population": "all %d launches of kernels whose name contains the pattern, in the profiled command" % len(f),
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py "
+                   + ("" if config == "cfg2" else "--config %s " % config) +
                    "--steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-sample-call (two separate passes)",
         "fetch_size_bytes_raw": 1024.0 * sum(f) / len(f),
         "write_size_bytes": 1024.0 * sum(w) / len(w),
