@@ -89,6 +89,31 @@ def test_conv16_fused_gn_silu_concat_temb_residual_stats(cdx_mod):
     assert torch.allclose(r2.cpu().double(), (wg.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=5e-3)
 
 
+@pytest.mark.parametrize("B,ci,co,H,W,k", [(1, 64, 136, 22, 40, 3), (2, 32, 64, 10, 18, 1), (1, 64, 192, 40, 24, 3), (2, 32, 96, 12, 12, 3),
+                                          (1, 32, 66, 9, 33, 3)])
+def test_conv16_ragged_tiles_output_and_sums(cdx_mod, B, ci, co, H, W, k):
+    """Partial spatial tiles and partial channel blocks through the accumulator-layout epilogue (packed channel pairs,
+    stores dropped by the bounded buffer resource, per-lane GroupNorm sums): pixels / channels outside the tensor are neither
+    written nor counted.  The output buffer is wider than cout and pre-filled: the padding must survive."""
+    ops = cdx_mod.ops
+    x = rnd(B, ci, H, W, seed=70)
+    w = rnd(co, ci, k, k, seed=71, scale=1.0 / math.sqrt(ci * k * k))
+    bias = rnd(co, seed=72) + 2.0
+    want = F.conv2d(h(x), h(w), bias.double(), padding=k // 2)
+    pc = ops.PackedConv16(w.numpy(), bias.numpy(), ci)
+    ld = (co + 7) // 4 * 4
+    out, st = ops.conv16(pc, nhwc16(x), want_stats=True, out_ld=ld)
+    if out.shape[-1] > co:
+        assert (out[..., co:] == 0).all()                      # ops.conv16 zero-fills the padding before the launch
+    got = nchw(out[..., :co].contiguous())
+    assert (got - want).abs().max().item() <= 6e-4 * want.abs().max().item()
+    G = 2
+    _, _, m2, r2 = ops.gn_finalize(st, None, H * W, torch.ones(co).cuda(), torch.zeros(co).cuda(), G, want_moments=True)
+    wg = want.reshape(B, G, -1)
+    assert (m2.cpu().double() - wg.mean(-1)).abs().max().item() <= 1e-5 * max(1.0, wg.abs().max().item())
+    assert torch.allclose(r2.cpu().double(), (wg.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-5)
+
+
 def test_conv16_fp32_source_and_output(cdx_mod):
     """conv_in reads the sampler's float32 x_t buffer (8 channels, 6 used); conv_out writes the float32 eps buffer."""
     ops = cdx_mod.ops
