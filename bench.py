@@ -258,6 +258,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="images (cfg5: tiles) per GPU and sampler call; default: the config's per-GPU batch")
     ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--graph", action="store_true", help="replay each UNet forward as one hipGraph launch (Sampler(use_graph=True): host-bound sizes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sample-call", action="store_true", help="skip the extra timing of one complete Sampler.sample()")
@@ -294,6 +295,7 @@ def main():
     job = cdx.shard.ShardJob(images_per_gpu * world, args.config, rank=rank, world=world, device=f"cuda:{local}",
                              images_per_call=images_per_gpu, config=(cfg, run), unet_kw={"split": False} if args.no_split else None)
     sampler, net = job.sampler, job.sampler.unet
+    sampler.use_graph = bool(args.graph)
     sync = torch.cuda.synchronize
 
     # inputs resident in HBM before the timed region: Sampler.begin() loads cond and draws x_T
@@ -337,7 +339,8 @@ def main():
                                                        f"overlap {run['overlap']})" if tiled else "")),
                    "images_per_gpu": B / tiles_per_image, "global_batch": B * world, "image": f"{cfg['image_size']}x{cfg['image_size']}x3",
                    "sampler_steps_per_image": run["steps"], "parallelism": f"replica x{world} (no collective)",
-                   "timed": "Sampler.step() x steps (cdx.sampler), shard + timing from cdx.shard.ShardJob / timed_region"},
+                   "timed": "Sampler.step() x steps (cdx.sampler), shard + timing from cdx.shard.ShardJob / timed_region"
+                            + (", UNet forward replayed as one hipGraph per step" if args.graph else "")},
         "algorithmic_gflop_per_step": round(total_flops / 1e9, 1),
         "algorithmic_tflops_whole_step": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
     }
