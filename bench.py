@@ -121,6 +121,29 @@ def kernel_model(variant) -> dict:
             "peak": FP32_MFMA_PEAK_TFLOPS, "wino": False, "flops_per_mfma_cycle": 64.0, "pmc_pattern": "conv_kernel<cdx::ConvCfg<%d, %d, %d, " % variant[:3]}
 
 
+def find_traffic_digest(pattern, sha, workload, directory=None):
+    """The committed PMC traffic digest that may be quoted for this run: same kernel (name pattern), same build of the kernel
+    sources (csrc hash) and same workload (a digest is an average over the launches of ONE bench command; digests without a
+    "config" field predate the check and were taken on cfg2).  Returns (file name, digest, None) or (None, None, description of
+    the newest digest of the same kernel and workload from ANOTHER build, or None)."""
+    directory = directory or os.path.join(ROOT, "profiles")
+    stale = None
+    for name in sorted(os.listdir(directory), reverse=True):
+        if "_traffic" not in name or not name.endswith(".json"):
+            continue
+        try:
+            tr = json.load(open(os.path.join(directory, name)))
+        except (OSError, ValueError):
+            continue
+        if tr.get("pattern") != pattern or tr.get("config", "cfg2") != workload:
+            continue
+        if tr.get("csrc_sha16") == sha:
+            return name, tr, None
+        if stale is None:
+            stale = {"file": f"profiles/{name}", "csrc_sha16": tr.get("csrc_sha16"), "hbm_bytes_per_launch": round(tr["hbm_bytes_per_launch"])}
+    return None, None, stale
+
+
 def measure_dominant_kernel(plan, torch, reps=3, workload="cfg2"):
     """Per-launch HIP-event timing of every conv launch of one forward; returns the roofline object for the
     kernel symbol with the most FLOPs, plus a per-variant table."""
@@ -178,24 +201,13 @@ def measure_dominant_kernel(plan, torch, reps=3, workload="cfg2"):
     sha = csrc_sha16()
     roof["csrc_sha16"] = sha
     roof["pmc_pattern"] = km["pmc_pattern"]
-    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-        if "_traffic" not in name or not name.endswith(".json"):
-            continue
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", name)))
-        except (OSError, ValueError):
-            continue
-        # (a digest is an average over the launches of ONE workload's command: another config's launches of the same kernel
-        # symbol have other shapes -- digests without a "config" field predate the check and were taken on cfg2)
-        same_kernel = tr.get("pattern") == km["pmc_pattern"] and tr.get("config", "cfg2") == workload
-        if same_kernel and tr.get("csrc_sha16") == sha:
-            roof["traffic"] = round(tr["hbm_bytes_per_launch"])
-            roof["traffic_over_algorithmic"] = round(tr["hbm_bytes_per_launch"] / roof["algorithmic_bytes_per_launch"], 3)
-            roof["traffic_source"] = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build: 2 x FETCH + WRITE)"
-            break
-        if same_kernel and "traffic_from_other_build" not in roof:
-            roof["traffic_from_other_build"] = {"file": f"profiles/{name}", "csrc_sha16": tr.get("csrc_sha16"),
-                                                "hbm_bytes_per_launch": round(tr["hbm_bytes_per_launch"])}
+    name, tr, stale = find_traffic_digest(km["pmc_pattern"], sha, workload)
+    if tr is not None:
+        roof["traffic"] = round(tr["hbm_bytes_per_launch"])
+        roof["traffic_over_algorithmic"] = round(tr["hbm_bytes_per_launch"] / roof["algorithmic_bytes_per_launch"], 3)
+        roof["traffic_source"] = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build: 2 x FETCH + WRITE)"
+    elif stale is not None:
+        roof["traffic_from_other_build"] = stale
     per_variant = {"k%ds%d_tw%d_%s" % k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                          "ms_per_forward": round(v["ms"] / reps, 3)}
                    for k, v in sorted(table.items(), key=lambda kv: -kv[1]["flops"])}
