@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include "conv16_kernel.h"
+#include "conv_kpar_kernel.h"
 
 using namespace cdx;
 
@@ -41,6 +42,12 @@ int validate(const cdx_conv_f16_args* a) {
 // of a batch-16 level leave most of the 256 CUs without a workgroup (16^2: 32 tiles x cout / 128)
 int f16_mt(const cdx_conv_f16_args* a) { return (a->stride == 2 || (a->wout >= 8 && a->wout < 32)) ? 2 : 4; }
 
+// 8 pixels wide, stride 1, 16-bit in and out: the chunk-parallel tile (conv_kpar_kernel.h; 4 GroupNorm-sum slots per tile)
+bool f16_kpar(const cdx_conv_f16_args* a) {
+    return a->stride == 1 && a->wout >= 8 && a->wout < 16 && !a->src_is_f32 && !a->out_is_f32 && (a->c0 % 8) == 0 && (a->c1 % 8) == 0 &&
+           (a->cout % 4) == 0;
+}
+
 void tile_grid(const cdx_conv_f16_args* a, int& logtw, int& tx, int& ty) {
     logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : a->wout >= 8 ? 3 : 2;
     const int bm = 32 * f16_mt(a), tw = 1 << logtw, th = bm / tw;
@@ -51,6 +58,12 @@ void tile_grid(const cdx_conv_f16_args* a, int& logtw, int& tx, int& ty) {
 
 namespace cdx {
 int conv16_dispatch_bf16(int ks, int stride, int logtw, const Conv16Params& p, hipStream_t stream);
+int conv16_kpar_dispatch_bf16(int ks, const Conv16Params& p, hipStream_t stream);
+int conv16_kpar_dispatch(int ks, bool bf, const Conv16Params& p, hipStream_t stream) {
+    if (bf) return conv16_kpar_dispatch_bf16(ks, p, stream);
+    if (ks == 3) return conv_kpar_launch<KparCfg<3, 3, 0, 0>>(p, stream);
+    return conv_kpar_launch<KparCfg<1, 3, 0, 0>>(p, stream);
+}
 int conv16_dispatch(int ks, int stride, int logtw, bool bf, const Conv16Params& p, hipStream_t stream) {
 #ifdef CDX_TUNING
     // timing ablations of the dominant shape (libcdx_tune.so only), selected by flag bits 8..10
@@ -134,7 +147,7 @@ extern "C" int32_t cdx_conv_f16_stats_slots(const cdx_conv_f16_args* a) {
     if (validate(a)) return 0;
     int logtw, tx, ty;
     tile_grid(a, logtw, tx, ty);
-    return tx * ty * (conv16_tail_2x2(a->cout, f16_mt(a)) ? 2 : 1);
+    return tx * ty * (f16_kpar(a) ? 4 : conv16_tail_2x2(a->cout, f16_mt(a)) ? 2 : 1);
 }
 
 extern "C" int cdx_conv_f16(const cdx_conv_f16_args* a, void*, size_t, cdx_stream_t stream) {
@@ -163,6 +176,7 @@ extern "C" int cdx_conv_f16(const cdx_conv_f16_args* a, void*, size_t, cdx_strea
     int logtw;
     tile_grid(a, logtw, p.tiles_x, p.tiles_y);
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
+    if (f16_kpar(a)) return conv16_kpar_dispatch(a->ksize, (a->flags & CDX_CONV_BF16) != 0, p, static_cast<hipStream_t>(stream));
     return conv16_dispatch(a->ksize, a->stride, logtw, (a->flags & CDX_CONV_BF16) != 0, p, static_cast<hipStream_t>(stream));
 }
 

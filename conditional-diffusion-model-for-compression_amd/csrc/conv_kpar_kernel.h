@@ -17,11 +17,17 @@
 
 namespace cdx {
 
-template <int KS_, int LOGTW_>
+// SPLIT = 0: the same tile for the 16-bit storage modes (fp16, BF = 1: bf16) -- one operand plane, one MFMA per (tap, 16
+// channels, M-tile), 16-bit sources / residual / output, GroupNorm sums from the float32 accumulators (cfg5's 8 x 8 level:
+// the 64-pixel x 128-channel tiles of conv16_kernel.h leave 3/4 of the CUs without a workgroup there).
+template <int KS_, int LOGTW_, int SPLIT_ = 1, int BF_ = 0>
 struct KparCfg {
-    static constexpr int KS = KS_, LOGTW = LOGTW_, TAPS = KS * KS, PAD = KS / 2;
+    static constexpr int KS = KS_, LOGTW = LOGTW_, TAPS = KS * KS, PAD = KS / 2, SPLIT = SPLIT_, BF = BF_;
+    static_assert(!(SPLIT && BF), "the split operands are fp16");
+    using H = std::conditional_t<BF != 0, __bf16, _Float16>;
+    static constexpr int PLANES = SPLIT ? 2 : 1;
     static constexpr int TW = 1 << LOGTW, MT = 2, BM = 64, TH = BM / TW, RPM = 32 / TW;
-    static constexpr int KC = 32, PSH = 2 * KC + 8;
+    static constexpr int KC = 32, PSH = PLANES * KC + 8;
     static constexpr int HH = TH + KS - 1, HW = TW + KS - 1;
     static constexpr int RSH = ((HW * PSH + 127) / 128) * 128;
     static constexpr int LDS_HALVES = HH * RSH;                    // per WAVE
@@ -29,17 +35,20 @@ struct KparCfg {
     static constexpr int NPASS = (NPIX + 15) / 16;                 // 16 pixel slots x 4 channel octets per pass and wave
     static constexpr int GPC = TAPS * 2;
     static constexpr int PF = GPC < 3 ? GPC : 3;
-    static_assert(TW <= 16 && 4 * LDS_HALVES * 2 <= 80 * 1024, "two workgroups per CU");
-    static_assert(4 * LDS_HALVES * 2 >= 4 * 32 * 64 * 4, "the halo images double as the reduction scratch");
+    static constexpr int SCRATCH_HALVES = 4 * 32 * 64 * 2;         // the halo images double as the reduction scratch (32 KiB of floats)
+    static constexpr int LDS_TOTAL = 4 * LDS_HALVES > SCRATCH_HALVES ? 4 * LDS_HALVES : SCRATCH_HALVES;
+    static_assert(TW <= 16 && LDS_TOTAL * 2 <= 80 * 1024, "two workgroups per CU");
 };
 
 template <class C, int STG>
 __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p) {
     constexpr bool kGN = STG == 1 || STG == 2, kSILU = STG == 2 || STG == 3;
     constexpr int KC = C::KC, PSH = C::PSH, RSH = C::RSH, TAPS = C::TAPS, MT = C::MT, NPASS = C::NPASS, GPC = C::GPC, PF = C::PF;
-    using H = _Float16;
-    using h8 = f16x8;
-    __shared__ __attribute__((aligned(16))) H lds_all[4 * C::LDS_HALVES];
+    using H = typename C::H;
+    using h8 = __attribute__((ext_vector_type(8))) H;
+    using h4 = __attribute__((ext_vector_type(4))) H;
+    constexpr unsigned ES = C::SPLIT ? 4u : 2u;                    // bytes per source / residual / output element
+    __shared__ __attribute__((aligned(16))) H lds_all[C::LDS_TOTAL];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,10 +84,10 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
     int cur_src = -1;
     auto bind_source = [&](int sidx) {
         const unsigned cs = (unsigned)p.csrc[sidx];
-        const size_t bytes = (size_t)p.B * p.Hin * p.Win * cs * 4u;
+        const size_t bytes = (size_t)p.B * p.Hin * p.Win * cs * ES;
         srs = buf_rsrc(p.src[sidx], bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes);
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) voff[i] = ((unsigned)soff[i] * cs + 8u * (unsigned)q) * 4u;
+        for (int i = 0; i < NPASS; ++i) voff[i] = ((unsigned)soff[i] * cs + 8u * (unsigned)q) * ES;
         cur_src = sidx;
     };
     auto issue_loads = [&](int chunk) {
@@ -87,14 +96,20 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
         const int cc = s ? chunk - p.nchunk0 : chunk;
         const int cl = cc * KC + q * 8;
         cvalid = cl < p.csrc[s];
-        const unsigned so = (unsigned)cc * (unsigned)KC * 4u;
+        const unsigned so = (unsigned)cc * (unsigned)KC * ES;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            const f32x4 v0 = buf_load4(srs, voff[i], so), v1 = buf_load4(srs, voff[i] + 16u, so);
+            if constexpr (C::SPLIT) {
+                const f32x4 v0 = buf_load4(srs, voff[i], so), v1 = buf_load4(srs, voff[i] + 16u, so);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                pre[i][e] = v0[e];
-                pre[i][4 + e] = v1[e];
+                for (int e = 0; e < 4; ++e) {
+                    pre[i][e] = v0[e];
+                    pre[i][4 + e] = v1[e];
+                }
+            } else {
+                const h8 v = __builtin_bit_cast(h8, buf_load4(srs, voff[i], so));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pre[i][e] = (float)v[e];
             }
         }
         if constexpr (kGN) {
@@ -124,21 +139,30 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
                 if constexpr (kSILU) v[k] = silu16_f(v[k]);
                 v[k] = __builtin_amdgcn_fmed3f(v[k], -bound, bound);
             }
-            o[e / 2] = pack_hi_f16(v[0], v[1]);                    // hi pair, lo pair = RN(v - hi) by mixed-precision FMA
-            ol[e / 2] = pack_lo_f16(o[e / 2], v[0], v[1]);
+            if constexpr (C::BF) {
+                using b2 = __attribute__((ext_vector_type(2))) __bf16;
+                o[e / 2] = __builtin_bit_cast(unsigned, b2{(__bf16)v[0], (__bf16)v[1]});
+            } else {
+                o[e / 2] = pack_hi_f16(v[0], v[1]);                // hi pair, lo pair = RN(v - hi) by mixed-precision FMA
+                if constexpr (C::SPLIT) ol[e / 2] = pack_lo_f16(o[e / 2], v[0], v[1]);
+            }
         }
         // slots past the halo's last pixel dump into the pad bytes of the lane's pass-0 pixel (no exec-mask branch)
         const bool real = (i + 1) * 16 <= C::NPIX || hp < C::NPIX;
-        const int off = real ? hy * RSH + hx * PSH + q * 8 : (pl / C::HW) * RSH + (pl % C::HW) * PSH + 2 * KC;
-        *reinterpret_cast<u4*>(&lds[off]) = o;
-        if (real) *reinterpret_cast<u4*>(&lds[off + KC]) = ol;
+        const int off = real ? hy * RSH + hx * PSH + q * 8 : (pl / C::HW) * RSH + (pl % C::HW) * PSH + C::PLANES * KC;
+        if constexpr (C::SPLIT) {
+            *reinterpret_cast<u4*>(&lds[off]) = o;
+            if (real) *reinterpret_cast<u4*>(&lds[off + KC]) = ol;
+        } else {
+            if (real) *reinterpret_cast<u4*>(&lds[off]) = o;       // (a 16-byte dump would not fit the 16 pad bytes' alignment: skip it)
+        }
     };
 
     // ---- MFMA operand addressing ----
     const int li = lane & 31, lh = lane >> 5;
     const int a_base = (li >> C::LOGTW) * RSH + (li & (C::TW - 1)) * PSH + lh * 8;
     const int ntile = blockIdx.y;
-    constexpr int GH = 1024;                                       // halves per group: hi | lo fragments
+    constexpr int GH = 512 * C::PLANES;                            // halves per group: hi | lo fragments (SPLIT)
     const H* __restrict__ wp = static_cast<const H*>(p.w) + ((size_t)ntile * p.nchunks * TAPS) * (2 * GH) + lane * 8;
     auto wfrag = [&](int chunk, int g, int plane) {                // fragment of (chunk, group) -- reads past the image end hit the zero pad
         return *reinterpret_cast<const h8*>(wp + ((size_t)chunk * GPC + g) * GH + plane * 512);
@@ -151,22 +175,25 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int n = ntile * 32 + li;
     if (wv == 0 && n < p.Cout) {                                   // bias + temb + residual through wave 0's accumulator init
-        const float inv = 1.0f / p.wunscale;
+        const float inv = C::SPLIT ? 1.0f / p.wunscale : 1.0f;
         float add = p.bias ? p.bias[n] : 0.f;
         if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
         add *= inv;
         if (p.residual) {
             const size_t first = (((size_t)b * p.Hout + oy0) * p.Wout + ox0) * p.Cout;
-            const size_t left = ((size_t)p.B * p.Hout * p.Wout * p.Cout - first) * 4;
-            const __amdgpu_buffer_rsrc_t rr = buf_rsrc(static_cast<const float*>(p.residual) + first, left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)left);
-            const unsigned voffr = ((unsigned)(4 * lh) * (unsigned)p.Cout + (unsigned)n) * 4u;
+            const size_t left = ((size_t)p.B * p.Hout * p.Wout * p.Cout - first) * ES;
+            const __amdgpu_buffer_rsrc_t rr = buf_rsrc(static_cast<const char*>(p.residual) + first * ES, left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)left);
+            const unsigned voffr = ((unsigned)(4 * lh) * (unsigned)p.Cout + (unsigned)n) * ES;
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int mb = t * 32 + 8 * (r >> 2) + (r & 3);
                     const unsigned pix = (unsigned)(mb >> C::LOGTW) * (unsigned)p.Wout + (unsigned)(mb & (C::TW - 1));
-                    acc[t][r] = fmaf(buf_load1(rr, voffr, pix * (unsigned)p.Cout * 4u), inv, add);
+                    float rv;
+                    if constexpr (C::SPLIT) rv = buf_load1(rr, voffr, pix * (unsigned)p.Cout * ES);
+                    else rv = (float)__builtin_bit_cast(H, __builtin_amdgcn_raw_buffer_load_b16(rr, voffr, pix * (unsigned)p.Cout * ES, 0));
+                    acc[t][r] = fmaf(rv, inv, add);
                 }
         } else {
 #pragma unroll
@@ -178,12 +205,11 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
 
     // ---- main loop: this wave's chunks ----
     if (wv < p.nchunks) {
-        h8 ring[PF][2];
+        h8 ring[PF][C::PLANES];
 #pragma unroll
-        for (int j = 0; j < PF; ++j) {
-            ring[j][0] = wfrag(wv, j, 0);
-            ring[j][1] = wfrag(wv, j, 1);
-        }
+        for (int j = 0; j < PF; ++j)
+#pragma unroll
+            for (int pl_ = 0; pl_ < C::PLANES; ++pl_) ring[j][pl_] = wfrag(wv, j, pl_);
         issue_loads(wv);
         for (int chunk = wv; chunk < p.nchunks; chunk += 4) {
 #pragma unroll
@@ -199,20 +225,24 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     a[t] = *reinterpret_cast<const h8*>(&lds[ab + (t * C::RPM + ky) * RSH + kx * PSH + j * 16]);
-                    al[t] = *reinterpret_cast<const h8*>(&lds[ab + (t * C::RPM + ky) * RSH + kx * PSH + KC + j * 16]);
+                    if constexpr (C::SPLIT) al[t] = *reinterpret_cast<const h8*>(&lds[ab + (t * C::RPM + ky) * RSH + kx * PSH + KC + j * 16]);
                 }
-                const h8 bq = ring[g % PF][0], bl = ring[g % PF][1];
+                const h8 bq = ring[g % PF][0];
+                h8 bl;
+                if constexpr (C::SPLIT) bl = ring[g % PF][1];
                 // refill: PF groups ahead in THIS WAVE's sequence (the next chunk of the wave is chunk + 4)
                 const int gn = g + PF < GPC ? g + PF : g + PF - GPC;
                 const int cn = g + PF < GPC ? chunk : (chunk + 4 < p.nchunks ? chunk + 4 : chunk);      // (last chunk: a harmless re-read)
-                ring[g % PF][0] = wfrag(cn, gn, 0);
-                ring[g % PF][1] = wfrag(cn, gn, 1);
+#pragma unroll
+                for (int pl_ = 0; pl_ < C::PLANES; ++pl_) ring[g % PF][pl_] = wfrag(cn, gn, pl_);
 #pragma unroll
                 for (int t = 0; t < MT; ++t) acc[t] = mfma_32x32x16(a[t], bq, acc[t]);
+                if constexpr (C::SPLIT) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) acc[t] = mfma_32x32x16(al[t], bq, acc[t]);
+                    for (int t = 0; t < MT; ++t) acc[t] = mfma_32x32x16(al[t], bq, acc[t]);
 #pragma unroll
-                for (int t = 0; t < MT; ++t) acc[t] = mfma_32x32x16(a[t], bl, acc[t]);
+                    for (int t = 0; t < MT; ++t) acc[t] = mfma_32x32x16(a[t], bl, acc[t]);
+                }
             }
         }
     }
@@ -228,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
     const int q4 = li & 3;
     const int cq = ntile * 32 + (li & ~3);
     const bool quad_ok = cq < p.Cout;
-    const float un = p.wunscale;
+    const float un = C::SPLIT ? p.wunscale : 1.0f;
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -246,7 +276,8 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
         const int oy = oy0 + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
         if (quad_ok && oy < p.Hout && ox < p.Wout) {
             const size_t pix = ((size_t)b * p.Hout + oy) * p.Wout + ox;
-            *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + pix * p.out_ld + cq) = f32x4{x[0], x[1], x[2], x[3]};
+            if constexpr (C::SPLIT) *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + pix * p.out_ld + cq) = f32x4{x[0], x[1], x[2], x[3]};
+            else *reinterpret_cast<h4*>(static_cast<H*>(p.out) + pix * p.out_ld + cq) = h4{(H)x[0], (H)x[1], (H)x[2], (H)x[3]};
             if (p.stats) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
