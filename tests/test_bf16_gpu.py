@@ -53,7 +53,8 @@ def test_bf16_weight_packer_rounds_to_nearest_even(cdx_mod):
 
 
 @pytest.mark.parametrize("case", [(2, 32, 128, 32, 32, 3, 1, False), (1, 64, 160, 16, 16, 3, 1, False), (2, 64, 96, 32, 32, 1, 1, False),
-                                  (2, 32, 128, 32, 32, 3, 2, False), (2, 32, 128, 16, 16, 3, 1, True), (1, 96, 128, 64, 64, 3, 1, False)],
+                                  (2, 32, 128, 32, 32, 3, 2, False), (2, 32, 128, 16, 16, 3, 1, True), (1, 96, 128, 64, 64, 3, 1, False),
+                                  (2, 160, 64, 8, 8, 3, 1, False), (3, 64, 100, 10, 12, 1, 1, False), (1, 256, 36, 9, 9, 3, 1, False)],      # 8 px wide: chunk-parallel tile
                          ids=lambda c: "x".join(map(str, c)))
 def test_conv_bf16_plain(cdx_mod, case):
     B, ci, co, H, W, k, s, up = case
@@ -84,6 +85,29 @@ def test_conv_bf16_fused_gn_silu_concat_temb_residual_stats(cdx_mod):
     sc, sh = ops.gn_stats(s0.float().contiguous(), s1.float().contiguous(), gamma.cuda(), beta.cuda(), G)
     pc = ops.PackedConv16(w.numpy(), bias.numpy(), c0, c1, bf16=True)
     out, st = ops.conv16(pc, s0, s1, gn=(sc, sh), silu=True, temb=temb.cuda(), temb_off=2, residual=nhwc16(res), want_stats=True)
+    assert out.dtype == torch.bfloat16
+    assert (nchw(out) - want).abs().max().item() <= 2e-2 * want.abs().max().item()
+    _, _, m2, r2 = ops.gn_finalize(st, None, H * W, torch.ones(co).cuda(), torch.zeros(co).cuda(), G, want_moments=True)
+    wg = want.reshape(B, G, -1)
+    assert (m2.cpu().double() - wg.mean(-1)).abs().max().item() <= 1.5e-2
+    assert torch.allclose(r2.cpu().double(), (wg.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=4e-2)
+
+
+def test_conv_bf16_chunk_parallel_tile_fused_with_sums(cdx_mod):
+    """8 x 8 level in bf16 storage (KparCfg<..., SPLIT = 0, BF = 1>): GroupNorm + SiLU on load, temb, residual and the four
+    GroupNorm-sum slots per tile, 5 input chunks over 4 waves (uneven split), ragged 10 x 9 image."""
+    ops = cdx_mod.ops
+    B, ci, co, H, W, G = 2, 160, 64, 10, 9, 32
+    x = rnd(B, ci, H, W, seed=40) * 1.5 + 0.3
+    gamma, beta = 1 + 0.2 * rnd(ci, seed=41), 0.3 * rnd(ci, seed=42)
+    w = rnd(co, ci, 3, 3, seed=43, scale=1.0 / math.sqrt(ci * 9))
+    bias, temb, res = rnd(co, seed=44), rnd(B, co, seed=45), rnd(B, co, H, W, seed=46)
+    act = b(F.silu(F.group_norm(b(x), G, gamma.double(), beta.double(), eps=1e-5)).float())
+    want = F.conv2d(act, b(w), bias.double(), padding=1) + temb.double()[:, :, None, None] + b(res)
+    s0 = nhwc16(x)
+    sc, sh = ops.gn_stats(s0.float().contiguous(), None, gamma.cuda(), beta.cuda(), G)
+    pc = ops.PackedConv16(w.numpy(), bias.numpy(), ci, bf16=True)
+    out, st = ops.conv16(pc, s0, gn=(sc, sh), silu=True, temb=temb.cuda(), residual=nhwc16(res), want_stats=True)
     assert out.dtype == torch.bfloat16
     assert (nchw(out) - want).abs().max().item() <= 2e-2 * want.abs().max().item()
     _, _, m2, r2 = ops.gn_finalize(st, None, H * W, torch.ones(co).cuda(), torch.zeros(co).cuda(), G, want_moments=True)
