@@ -18,12 +18,17 @@ loop here); the shard arithmetic (which images this rank decodes) and the barrie
 cdx.shard (ShardJob, timed_region), the driver the CPU gloo test exercises.  `sample_call` additionally times ONE
 complete Sampler.sample() of this rank's shard (x_T draw, all steps, export) after the step loop.
 
+`python bench.py --gpus N` with N > 1 and no launcher around it starts the N ranks itself (torch.distributed.run as a child
+process, before anything touches the GPU), forwards rank 0's JSON line and exits with the child's status.
+
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel symbol (the conv instantiation carrying most FLOPs): MFMA FLOPs it EXECUTES in
-                  one forward / the summed durations of its launches, measured with HIP events on the launch stream,
-                  against the MFMA peak of the instruction it runs on (fp32: 157.3 TFLOP/s).  `frac` <= 1 by
-                  construction; for the Winograd kernel the direct-convolution (algorithmic) FLOP rate is reported
-                  beside it as algorithmic_tflops / algorithmic_over_direct_peak.
+  roofline     -- the dominant kernel symbol (the conv instantiation carrying most FLOPs): `achieved` = ALGORITHMIC FLOPs of
+                  its launches in one forward / their summed durations (HIP events on the launch stream); `frac` (=
+                  `frac_algorithmic`) = achieved / dense peak of the MFMA instruction it issues.  The float32 path issues 3
+                  fp16 MFMAs per product (`emulation_factor` 3: frac <= 1/3); `mfma_pipe_utilisation` = the MFMA FLOPs it
+                  issues / the same peak.
+  strict_f32   -- the same step loop on the f32-input MFMA kernels only (UNet(split=False): direct + Winograd
+                  v_mfma_f32_32x32x2_f32), a few steps, timed in the same run: the conservative float32 number.
   cpu_baseline -- the stock-torch CPU oracle (oracle/, kind "port": the reference ships no sampler) timed
                   on this host's cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -180,14 +185,20 @@ def measure_dominant_kernel(plan, torch, reps=3, workload="cfg2"):
     algorithmic = d["flops"] / (d["ms"] * 1e-3) / 1e12
     executed = algorithmic * km["executed_per_algorithmic"]
     peak = km["peak"]
-    roof = {"bound": "mfma", "achieved": round(executed, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(executed / peak, 4), "traffic": None,
+    ef = km["executed_per_algorithmic"]
+    # achieved = ALGORITHMIC FLOPs of the launches / their measured time; frac = achieved / peak of the pipe the
+    # kernel runs on.  A kernel that emulates float32 products with 3 fp16 MFMAs (emulation_factor 3) can reach at most 1/3 of
+    # that peak in algorithmic terms; mfma_pipe_utilisation = executed MFMA FLOPs / peak says how busy it keeps the pipe.
+    roof = {"bound": "mfma", "achieved": round(algorithmic, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(algorithmic / peak, 4), "traffic": None,
+            "frac_algorithmic": round(algorithmic / peak, 4),
+            "emulation_factor": ef, "mfma_pipe_utilisation": round(executed / peak, 4), "executed_tflops": round(executed, 2),
             "kernel": km["name"] + " [ksize %d stride %d log2TW %d tile %s]" % dom,
-            "flop_accounting": "achieved = MFMA FLOPs the kernel EXECUTES / measured time (frac <= 1 against the peak of the "
-                               "instruction it runs on)"
-                               + ("; Winograd F(2x2,3x3) executes 1/2.25 of the direct-convolution FLOPs (2*Cin*Cout*9*H*W*B), "
-                                  "whose rate is algorithmic_tflops" if km["wino"] else ""),
-            "algorithmic_tflops": round(algorithmic, 2), "algorithmic_over_direct_peak": round(algorithmic / peak, 4),
+            "flop_accounting": "achieved / frac / frac_algorithmic = algorithmic (direct-convolution) FLOPs 2*Cin*Cout*k*k*H*W*B per second "
+                               "against the dense peak of the MFMA instruction the kernel issues; executed_tflops / mfma_pipe_utilisation = "
+                               "the MFMA FLOPs it actually issues (emulation_factor x algorithmic) against the same peak"
+                               + ("; Winograd F(2x2,3x3) executes 1/2.25 of the direct-convolution FLOPs" if km["wino"] else ""),
+            "algorithmic_tflops": round(algorithmic, 2), "algorithmic_over_f32_mfma_peak": round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 4),
             "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_forward": d["launches"] // reps,
             "flop_share_of_forward": round(d["flops"] / sum(v["flops"] for v in table.values()), 4),
             "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
@@ -263,7 +274,51 @@ def cpu_baseline(cfg, run, params, cond_cpu, torch, budget_s=25.0):
                       + f"; {sec_per_step:.2f} s/step, float32, torch {torch.__version__} CPU"}
 
 
-def main():
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list, entry: str | None = None) -> int:
+    """Start n ranks of `entry` (default: this file) under torch.distributed.run as ONE child process and return its exit
+    status.  The caller must not have touched the GPU (no exec, no fork of an initialised process: the child is a fresh
+    interpreter); stdout / stderr are inherited, so rank 0's JSON line reaches the caller's stdout unchanged."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), entry or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def strict_f32_leg(cdx, torch, job, cfg, run, B, tiles_per_image, total_flops, tiled, nsteps=5):
+    """The same step loop on the f32-input MFMA kernels only (UNet(split=False)): no fp16 operands anywhere, a few steps
+    (every step costs the same), timed in this run so that the conservative float32 number is the driver's own."""
+    net = cdx.UNet(cfg, job.params, device=job.device, split=False)
+    smp = cdx.Sampler(net, method=run["method"])
+    if tiled:
+        conds, xts, _, _ = cdx.tiling.tile_batch(net, job.cond(job.lo, 1), run["overlap"], job.seed, job.lo)
+        reps_ = -(-B // conds.shape[0])
+        st = smp.begin(conds.repeat(reps_, 1, 1, 1)[:B].contiguous(), run["steps"], seed=job.seed, x_T=xts.repeat(reps_, 1, 1, 1)[:B].contiguous())
+    else:
+        st = smp.begin(job.cond(job.lo, B), run["steps"], seed=job.seed, first_image=job.lo)
+    smp.step(st, 0)
+    sec = cdx.timed_region(lambda: [smp.step(st, 1 + k) for k in range(nsteps)], None, torch.cuda.synchronize)
+    assert torch.isfinite(st.plan.xin).all()
+    ms = sec / nsteps * 1e3
+    tf = total_flops / (ms * 1e-3) / 1e12
+    out = {"images_per_s": round((B / tiles_per_image) / (run["steps"] * ms * 1e-3), 4), "ms_per_step": round(ms, 3), "steps": nsteps,
+           "algorithmic_tflops_whole_step": round(tf, 2), "frac_of_f32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "peak": FP32_MFMA_PEAK_TFLOPS,
+           "arithmetic": "float32 operands on v_mfma_f32_32x32x2_f32 (direct + Winograd F(2x2,3x3): algorithmic rate can exceed the direct-convolution peak)"}
+    del smp, st, net
+    torch.cuda.empty_cache()
+    return out
+
+
+def main(argv=None, make_sampler=None, dist_backend="nccl"):
+    """make_sampler / dist_backend: test injection (tests/bench_entry_oracle.py runs this same function on CPU ranks over gloo
+    with a stand-in sampler to exercise the launch, shard and timing path without a GPU); the product run passes neither."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -274,27 +329,37 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sample-call", action="store_true", help="skip the extra timing of one complete Sampler.sample()")
+    ap.add_argument("--no-strict-f32", action="store_true", help="skip the extra step loop on the f32-input MFMA kernels (strict_f32)")
     ap.add_argument("--dtype", default=None, choices=["fp32", "fp16", "bf16"], help="override the config's storage dtype (e.g. cfg2 in fp16 / bf16)")
     ap.add_argument("--no-split", action="store_true", help="A/B: float32 layers on the f32-input MFMA kernels only (no fp16 hi|lo split tile)")
     ap.add_argument("--details", action="store_true", help="print the per-variant conv table to stderr")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the ranks ourselves, BEFORE importing torch or touching the GPU in this process
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
 
     import torch
     import cdx
 
+    injected = make_sampler is not None
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not injected:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        torch.cuda.set_device(local)
     dist = None
     if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run: RCCL for the barrier / max-reduce only
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if injected:
+            dist.init_process_group(dist_backend)
+        else:
+            dist.init_process_group(dist_backend, device_id=torch.device("cuda", local))
 
     # This rank's shard of the job: weak scaling, B units per GPU (cdx.shard owns the rank arithmetic).
     cfg, run = cdx.named_config(args.config)
@@ -304,11 +369,14 @@ def main():
     tiled = "image" in run
     tiles_per_image = len(cdx.tile_origins(run["image"], cfg["image_size"], run["overlap"])) ** 2 if tiled else 1
     images_per_gpu = 1 if tiled else B            # cfg5: the step loop runs B TILES; sample_call decodes one whole image
-    job = cdx.shard.ShardJob(images_per_gpu * world, args.config, rank=rank, world=world, device=f"cuda:{local}",
-                             images_per_call=images_per_gpu, config=(cfg, run), unet_kw={"split": False} if args.no_split else None)
-    sampler, net = job.sampler, job.sampler.unet
+    device = None if injected else f"cuda:{local}"
+    job = cdx.shard.ShardJob(images_per_gpu * world, args.config, rank=rank, world=world, device=device,
+                             images_per_call=images_per_gpu, config=(cfg, run), unet_kw={"split": False} if args.no_split else None,
+                             make_sampler=make_sampler)
+    sampler = job.sampler
+    net = getattr(sampler, "unet", None)
     sampler.use_graph = bool(args.graph)
-    sync = torch.cuda.synchronize
+    sync = None if injected else torch.cuda.synchronize
 
     # inputs resident in HBM before the timed region: Sampler.begin() loads cond and draws x_T
     if tiled:
@@ -320,9 +388,9 @@ def main():
         state = sampler.begin(job.cond(job.lo, B), run["steps"], seed=job.seed, first_image=job.lo)
     plan = state.plan
 
-    def steps(k0, n):
+    def steps(k0, n, smp=sampler, st=state):
         for k in range(k0, k0 + n):
-            sampler.step(state, k % run["steps"])      # the function Sampler.sample() loops over
+            smp.step(st, k % run["steps"])      # the function Sampler.sample() loops over
 
     steps(0, args.warmup)
     elapsed = cdx.timed_region(lambda: steps(args.warmup, args.steps), dist, sync)
@@ -330,7 +398,7 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     images_per_s = (B * world / tiles_per_image) / (run["steps"] * ms_per_step * 1e-3)
-    fl = plan_flops(plan)
+    fl = plan_flops(plan) if not injected else {"conv": 0.0}
     total_flops = sum(fl.values())
     line = {
         "metric": ("decoded images/sec (whole node), 256x256 100-step DDIM" if args.config in ("cfg2", "cfg3") else
@@ -367,12 +435,16 @@ def main():
                                "images_per_s": round(n_img / sec, 4),
                                "ms_per_step_equiv": round(sec * 1e3 / (run["steps"] * (-(-tiles_per_image // B) if tiled else 1)), 3)}
         assert all(torch.isfinite(v).all() for v in out.values())
-    if rank == 0 and not args.no_roofline:
+    if injected:
+        line["backend"] = "injected sampler (test of the launch / shard / timing path; not a measurement of the product)"
+    if rank == 0 and not args.no_roofline and not injected:
         roof, table = measure_dominant_kernel(plan, torch, workload=args.config)
         line["roofline"] = roof
         if args.details:
             print(json.dumps({"conv_variants": table, "flops": fl}, indent=1), file=sys.stderr)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not injected and not args.no_strict_f32 and not args.no_split and cfg["dtype"] == "fp32":
+        line["strict_f32"] = strict_f32_leg(cdx, torch, job, cfg, run, B, tiles_per_image, total_flops, tiled)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not injected:
         c1 = job.cond(0, 1).cpu()
         if tiled:
             c1 = c1[..., :cfg["image_size"] // 16, :cfg["image_size"] // 16].contiguous()

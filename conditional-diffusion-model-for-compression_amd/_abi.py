@@ -13,10 +13,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/conv_bench.py only); the product always loads libcdx.so.
 LIB_PATH = os.path.join(_HERE, "libcdx_tune.so" if os.environ.get("CDX_TUNE") == "1" else "libcdx.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 CONV_UPSAMPLE2X, CONV_GN, CONV_SILU, CONV_BF16 = 1, 2, 4, 8
 LINEAR_SILU_IN = 1
 CONV_KC = 32
+AMAX_WORDS = 16          # words per image of the amax arrays (cdx.h CDX_AMAX_WORDS)
 
 _f = C.c_void_p   # device / host pointers are passed as raw addresses
 _i = C.c_int32
@@ -28,7 +29,8 @@ class ConvArgs(C.Structure):
                 ("cout", _i), ("ksize", _i), ("stride", _i), ("flags", _i),
                 ("wpacked", _f), ("bias", _f), ("gn_scale", _f), ("gn_shift", _f),
                 ("temb", _f), ("temb_ld", _i), ("residual", _f), ("out", _f), ("out_ld", _i), ("wpacked_wino", _f), ("stats_out", _f),
-                ("wpacked_split", _f), ("wsplit_unscale", C.c_float)]
+                ("wpacked_split", _f), ("wsplit_unscale", C.c_float), ("gn_exp", _i),
+                ("src_amax0", _f), ("src_amax1", _f), ("stats_slots", _i), ("amax_out", _f)]
 
 
 class ConvF16Args(C.Structure):
@@ -43,13 +45,13 @@ class ConvF16Args(C.Structure):
 class GnStatsArgs(C.Structure):
     _fields_ = [("src0", _f), ("src1", _f), ("c0", _i), ("c1", _i), ("batch", _i), ("hw", _i),
                 ("groups", _i), ("eps", C.c_float), ("gamma", _f), ("beta", _f),
-                ("scale", _f), ("shift", _f), ("mean", _f), ("rstd", _f)]
+                ("scale", _f), ("shift", _f), ("mean", _f), ("rstd", _f), ("out_exp", _i)]
 
 
 class GnFinalizeArgs(C.Structure):
     _fields_ = [("part0", _f), ("slots0", _i), ("c0", _i), ("part1", _f), ("slots1", _i), ("c1", _i),
                 ("batch", _i), ("hw", _i), ("groups", _i), ("eps", C.c_float), ("gamma", _f), ("beta", _f),
-                ("scale", _f), ("shift", _f), ("mean", _f), ("rstd", _f)]
+                ("scale", _f), ("shift", _f), ("mean", _f), ("rstd", _f), ("out_exp", _i)]
 
 
 class AttnArgs(C.Structure):
@@ -95,6 +97,18 @@ class RansDecodeArgs(C.Structure):
                 ("alphabet", _i), ("prob_bits", _i), ("qmax", _i), ("step", C.c_float), ("out", _f), ("symbols", _f), ("status", _f)]
 
 
+class AmaxArgs(C.Structure):
+    _fields_ = [("x", _f), ("x_ld", _i), ("batch", _i), ("n", _i), ("channels", _i), ("out", _f)]
+
+
+class FillU32Args(C.Structure):
+    _fields_ = [("x", _f), ("n", C.c_int64), ("value", C.c_uint32)]
+
+
+class CheckFiniteArgs(C.Structure):
+    _fields_ = [("x", _f), ("x_ld", _i), ("rows", C.c_int64), ("channels", _i), ("limit", C.c_float), ("status", _f)]
+
+
 class TileBlendArgs(C.Structure):
     _fields_ = [("tiles", _f), ("batch", _i), ("channels", _i), ("tile", _i), ("ny", _i), ("nx", _i),
                 ("y0", _f), ("x0", _f), ("h", _i), ("w", _i), ("out", _f)]
@@ -117,16 +131,20 @@ OPS = {
     "export_image_f32": ExportImageArgs,
     "tile_blend_f32": TileBlendArgs,
     "rans_decode_i16": RansDecodeArgs,
+    "amax_f32": AmaxArgs,
+    "fill_u32": FillU32Args,
+    "check_finite_f32": CheckFiniteArgs,
 }
 
 # every exported symbol include/cdx.h declares (checked by tests/test_abi.py without a GPU)
+TILE_SPLIT = 11
 TILE_NAMES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "64x128", 4: "64x64", 5: "S32x32", 6: "S64x32", 7: "wino128x128", 8: "small256x4", 9: "small256x4valu", 10: "cin8_128x128", 11: "split128x128"}
 
 EXPORTS = (["cdx_abi_version", "cdx_strerror", "cdx_launch_count",
             "cdx_conv_packed_floats", "cdx_conv_pack_weights_f32", "cdx_conv_select_tile", "cdx_conv_f32_tile",
             "cdx_conv_stats_slots", "cdx_conv_wino_packed_floats", "cdx_conv_pack_weights_wino_f32",
             "cdx_conv_f16_stats_slots", "cdx_conv_f16_packed_halves", "cdx_conv_pack_weights_f16",
-            "cdx_conv_split_packed_halves", "cdx_conv_pack_weights_split_f16", "cdx_conv_pack_weights_bf16"]
+            "cdx_conv_split_packed_halves", "cdx_conv_pack_weights_split_f16", "cdx_conv_pack_weights_bf16", "cdx_gn_act_exp"]
            + [f"cdx_{op}" for op in OPS] + [f"cdx_{op}_workspace" for op in OPS])
 
 _lib = None
@@ -177,6 +195,8 @@ def lib() -> C.CDLL:
     L.cdx_conv_stats_slots.argtypes = [C.POINTER(ConvArgs)]
     L.cdx_conv_f32_tile.restype = C.c_int
     L.cdx_conv_f32_tile.argtypes = [C.POINTER(ConvArgs), _i, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.cdx_gn_act_exp.restype = C.c_int32
+    L.cdx_gn_act_exp.argtypes = [_f, _f, _i, _i, _i]
     for op, st in OPS.items():
         fn = getattr(L, f"cdx_{op}")
         fn.restype = C.c_int
@@ -203,6 +223,14 @@ def call(op: str, args: C.Structure, ws_ptr: int, ws_bytes: int, stream: int) ->
 
 def workspace_bytes(op: str, args: C.Structure) -> int:
     return int(getattr(lib(), f"cdx_{op}_workspace")(C.byref(args)))
+
+
+def gn_act_exp(gamma, beta, groups: int, hw: int) -> int:
+    """cdx_gn_act_exp on host arrays: the static activation exponent of a GroupNorm-ed split-tile input (cdx.h)."""
+    import numpy as np
+    g = np.ascontiguousarray(gamma, dtype=np.float32)
+    b = np.ascontiguousarray(beta, dtype=np.float32)
+    return int(lib().cdx_gn_act_exp(g.ctypes.data, b.ctypes.data, g.size, groups, hw))
 
 
 def pack_conv_weights(w_oihw, c0: int, c1: int):

@@ -19,6 +19,7 @@ no host work to the sampling loop.  No CPU fallback.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 
 import numpy as np
@@ -100,43 +101,68 @@ class _CtxPlan:
         new = lambda *s: self._hold(torch.empty(*s, device=dev, dtype=torch.float32))      # noqa: E731
         self.z = self._hold(torch.zeros(batch, hz, wz, cc["latent_channels"], device=dev))
         stats_of = {}
+        # range bookkeeping of the split tiles, as in unet._Plan: one int32 word per (tensor, image), zeroed per run
+        split = net.split
+        self.amax_arena = self._hold(torch.zeros(8 + net.ups + cc["num_blocks"], batch, _abi.AMAX_WORDS, dtype=torch.int32, device=dev))
+        amax_slot, need_amax, produced = {}, set(), {}
 
-        def conv(name, src, *, gn=None, upsample=False, residual=None, normed_later=False, out_ld=None):
+        def amax_of(t):
+            if t.data_ptr() not in amax_slot:
+                amax_slot[t.data_ptr()] = self.amax_arena[len(amax_slot)]
+            return amax_slot[t.data_ptr()]
+
+        if split:
+            self.calls.append((_abi.lib().cdx_fill_u32, _abi.FillU32Args(self.amax_arena.data_ptr(), self.amax_arena.numel(), 0)))
+
+        def conv(name, src, *, norm=None, upsample=False, residual=None, normed_later=False, out_ld=None):
             pc = net.convs[name]
             B, h, w, _ = src.shape
             ho, wo = (2 * h, 2 * w) if upsample else (h, w)
             out = new(B, ho, wo, out_ld or pc.cout)
             if out.shape[-1] != pc.cout:
                 out.zero_()
-            a = ops.conv_args(pc, src, None, out, upsample=upsample, gn=gn, silu=gn is not None, residual=residual, out_ld=out_ld)
-            if normed_later:
+            gnp = (new(batch, src.shape[-1]), new(batch, src.shape[-1])) if norm is not None else None
+            a = ops.conv_args(pc, src, None, out, upsample=upsample, gn=gnp, silu=norm is not None, residual=residual, out_ld=out_ld)
+            if split and norm is not None:
+                a.gn_exp = _abi.gn_act_exp(net.host[norm + ".weight"], net.host[norm + ".bias"], g, h * w)
+                if _abi.lib().cdx_conv_select_tile(ctypes.byref(a)) != _abi.TILE_SPLIT:
+                    a.gn_exp = 0
+            elif split:
+                a.src_amax0 = amax_of(src).data_ptr()
+                if _abi.lib().cdx_conv_select_tile(ctypes.byref(a)) == _abi.TILE_SPLIT:
+                    if src.data_ptr() in produced:
+                        need_amax.add(src.data_ptr())
+                    else:      # the latent: caller data
+                        self.calls.append((_abi.lib().cdx_amax_f32, _abi.AmaxArgs(src.data_ptr(), src.shape[-1], B, h * w, src.shape[-1],
+                                                                                 amax_of(src).data_ptr())))
+                else:
+                    a.src_amax0 = None
+            if norm is not None:
+                ga = ops.gn_finalize_args(stats_of[src.data_ptr()], None, h * w, net.dev[norm + ".weight"], net.dev[norm + ".bias"],
+                                          g, gnp[0], gnp[1], out_exp=a.gn_exp)
+                self.calls.append((_abi.lib().cdx_gn_finalize_f32, ga))
+            if normed_later:      # (asked AFTER the range fields are set: they decide the tile, the tile the slots)
                 stats_of[out.data_ptr()] = self._hold(ops.conv_stats_buffer(a, dev))
+            produced[out.data_ptr()] = a
             self.calls.append((_abi.lib().cdx_conv_f32, a))
             return out
 
-        def gn(name, src):
-            c = src.shape[-1]
-            sc, sh = new(batch, c), new(batch, c)
-            a = ops.gn_finalize_args(stats_of[src.data_ptr()], None, src.shape[1] * src.shape[2], net.dev[name + ".weight"],
-                                     net.dev[name + ".bias"], g, sc, sh)
-            self.calls.append((_abi.lib().cdx_gn_finalize_f32, a))
-            return sc, sh
-
         h = conv("ctx.in", self.z, normed_later=True)
         for i in range(cc["num_blocks"]):
-            h = conv(f"ctx.block{i}.conv", h, gn=gn(f"ctx.block{i}.norm", h), residual=h, normed_later=True)
+            h = conv(f"ctx.block{i}.conv", h, norm=f"ctx.block{i}.norm", residual=h, normed_later=True)
         for u in range(net.ups):
             h = conv(f"ctx.up{u}", h, upsample=True, normed_later=True)
         pc = net.convs["ctx.out"]
-        self.out = conv("ctx.out", h, gn=gn("ctx.out.norm", h), out_ld=(pc.cout + 3) // 4 * 4)
+        self.out = conv("ctx.out", h, norm="ctx.out.norm", out_ld=(pc.cout + 3) // 4 * 4)
         self.cout = pc.cout
+        for k in need_amax:
+            produced[k].amax_out = amax_slot[k].data_ptr()
 
     def _hold(self, t):
         self._keep.append(t)
         return t
 
     def run(self):
-        import ctypes
         st = torch.cuda.current_stream(self.z.device).cuda_stream
         for fn, a in self.calls:
             rc = fn(ctypes.byref(a), None, 0, st)
@@ -166,13 +192,15 @@ class ContextNet:
         for k, shp in shapes.items():
             if k not in P or tuple(P[k].shape) != tuple(shp):
                 raise ValueError(f"context param {k}: expected shape {shp}")
-        self.convs, self.dev = {}, {}
+        self.convs, self.dev, self.host = {}, {}, {}
         for name, shp in shapes.items():
             if name.endswith(".weight") and len(shp) == 4:
                 base = name[:-7]
                 self.convs[base] = ops.PackedConv(P[name], P[base + ".bias"], shp[1], 0, self.device, split=split)
             elif ".norm" in name:
                 self.dev[name] = torch.from_numpy(np.ascontiguousarray(P[name])).to(self.device)
+                self.host[name] = P[name]
+        self.split = split
         self._plans = {}
 
     @torch.no_grad()

@@ -9,9 +9,10 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
 using namespace cdx;
 
 namespace cdx {
-bool conv_split_ok(const cdx_conv_args* a);                       // conv16.hip
+bool conv_split_ok(const cdx_conv_args* a);                       // conv_split.hip
 int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant = 0);
 int conv_split_slots_per_tile(const cdx_conv_args* a);
+int amax_launch(const float* x, int x_ld, int batch, int n, int channels, unsigned* out, hipStream_t stream);   // range.hip
 }  // namespace cdx
 
 namespace {
@@ -128,6 +129,9 @@ bool cin8_ok(const cdx_conv_args* a) {
     return a->ksize == 3 && a->stride == 1 && a->c0 <= 8 && a->c1 == 0 && a->wout >= 32 && a->cout > 4;
 }
 
+// the split tile's geometry depends on the layer (128 / 64 pixels, slots per tile), not on the id alone
+Tile split_tile(const cdx_conv_args* a) { return Tile{WCFG_SPLIT, (a->stride == 2 || a->wout < 32) ? 64 : 128, 128, conv_split_slots_per_tile(a)}; }
+
 // Tile-shape heuristic.  Depends on the LAYER shape only, never on the batch: a different tile changes the
 // summation order, and an image must decode to the same bits whatever batch / GPU shard it rides in.
 Tile select_tile(const cdx_conv_args* a) {
@@ -145,7 +149,7 @@ Tile select_tile(const cdx_conv_args* a) {
     // Layers at >= 32 pixels wide: the float32 product on the FP16 matrix pipe with split operands (3 MFMAs of 32 cycles
     // per 16 channels against 8 x 64 for the f32-input MFMA): same float32-level error, 2.4x less matrix-pipe time than
     // even the Winograd kernel.  Needs the wpacked_split image; otherwise the float32-MFMA kernels below are used.
-    if (conv_split_ok(a)) return Tile{WCFG_SPLIT, (a->stride == 2 || a->wout < 32) ? 64 : 128, 128, conv_split_slots_per_tile(a)};
+    if (conv_split_ok(a)) return split_tile(a);
     if (a->ksize == 3) {
         if (hw <= kSplitKMaxPixels) t = tile_of(a->stride == 1 && hw >= 256 ? WCFG_S64 : WCFG_S32);
         else if (cin8_ok(a)) t = tile_of(WCFG_CIN8);
@@ -182,6 +186,10 @@ int validate(const cdx_conv_args* a) {
     CDX_REQUIRE(aligned16(a->src0) && aligned16(a->src1) && aligned16(a->wpacked));
     if (a->flags & CDX_CONV_GN) CDX_REQUIRE(a->gn_scale && a->gn_shift && aligned16(a->gn_scale) && aligned16(a->gn_shift));
     if (a->wpacked_split) CDX_REQUIRE(aligned16(a->wpacked_split) && a->wsplit_unscale > 0.f);
+    CDX_REQUIRE(a->gn_exp >= -60 && a->gn_exp <= 60);
+    if (!(a->flags & CDX_CONV_GN)) CDX_REQUIRE(a->gn_exp == 0);
+    if (a->amax_out) CDX_REQUIRE((a->cout % 4) == 0 && (a->out_ld % 4) == 0 && aligned16(a->out));
+    CDX_REQUIRE(((reinterpret_cast<uintptr_t>(a->src_amax0) | reinterpret_cast<uintptr_t>(a->src_amax1) | reinterpret_cast<uintptr_t>(a->amax_out)) & 63u) == 0);
     if (a->temb) CDX_REQUIRE(a->temb_ld >= a->cout);
     if (a->stats_out) CDX_REQUIRE((a->cout % 4) == 0 && (a->out_ld % 4) == 0);   // sums are produced by the packed epilogue
     if (a->residual && (a->cout % 4) == 0) CDX_REQUIRE(aligned16(a->residual));
@@ -199,6 +207,14 @@ extern "C" int cdx_conv_select_tile(const cdx_conv_args* a) {
     return rc ? rc : select_tile(a).wcfg;
 }
 
+namespace {
+int slots_of(const cdx_conv_args* a, const Tile& t) {
+    const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : a->wout >= 8 ? 3 : 2;
+    const int tw = 1 << logtw, th = t.bm / tw;
+    return ceil_div(a->wout, tw) * ceil_div(a->hout, th) * t.wm;
+}
+}  // namespace
+
 extern "C" int32_t cdx_conv_stats_slots(const cdx_conv_args* a) {
     if (validate(a)) return 0;
     // the question is asked BEFORE the caller has a buffer to put into stats_out: answer for the launch WITH sums
@@ -206,10 +222,7 @@ extern "C" int32_t cdx_conv_stats_slots(const cdx_conv_args* a) {
     cdx_conv_args with_stats = *a;
     if (!with_stats.stats_out) with_stats.stats_out = reinterpret_cast<double*>(uintptr_t(16));
     if (validate(&with_stats)) return 0;
-    const Tile t = select_tile(&with_stats);
-    const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : a->wout >= 8 ? 3 : 2;
-    const int tw = 1 << logtw, th = t.bm / tw;
-    return ceil_div(a->wout, tw) * ceil_div(a->hout, th) * t.wm;
+    return slots_of(a, select_tile(&with_stats));
 }
 
 extern "C" int cdx_conv_f32(const cdx_conv_args* a, void* ws, size_t ws_bytes, cdx_stream_t stream) {
@@ -233,6 +246,7 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
 #endif
     Tile t = tile < 0 ? select_tile(a) : experimental ? Tile{tile, 128, 128, 1} : tile_of(tile);
     if (t.wcfg < 0 || (!experimental && !tile_allowed(a, t.wcfg))) return CDX_ENOTSUP;
+    if (t.wcfg == WCFG_SPLIT) t = split_tile(a);
     if (experimental && !(a->ksize == 3 && a->stride == 1)) return CDX_ENOTSUP;
     const int ups = (a->flags & CDX_CONV_UPSAMPLE2X) ? 1 : 0;
 
@@ -249,7 +263,9 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
     p.w = a->wpacked; p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift;
     p.temb = a->temb; p.temb_ld = a->temb_ld; p.residual = a->residual; p.out = a->out; p.out_ld = a->out_ld;
     p.stats = a->stats_out;
-    if (a->stats_out && tile >= 0 && tile != select_tile(a).wcfg) return CDX_EINVAL;   // slot count is defined for the library's own tile choice
+    if (a->stats_out && tile >= 0 && tile < 16 && tile != select_tile(a).wcfg) return CDX_EINVAL;   // slot count is defined for the library's own tile choice
+    // the buffer was sized by an earlier cdx_conv_stats_slots call: refuse to write a different number of slots into it
+    if (a->stats_out && !experimental) CDX_REQUIRE(a->stats_slots == slots_of(a, t));
 
     const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : a->wout >= 8 ? 3 : 2;
     const int tw = 1 << logtw, th = t.bm / tw;
@@ -258,17 +274,23 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
 
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (t.wcfg == WCFG_SPLIT) return conv_split_launch(a, st);
+    if (t.wcfg == WCFG_SPLIT) return conv_split_launch(a, st);      // (scales its activations by 2^gn_exp / amax; writes amax_out)
+    // the f32-input MFMA kernels take GroupNorm scale / shift at unit scale: a pre-multiplied pair belongs to the split tile
+    // (the host asks cdx_conv_select_tile first and passes out_exp = gn_exp = 0 otherwise)
+    CDX_REQUIRE(a->gn_exp == 0);
     if (t.wcfg == WCFG_WINO || (experimental && tile >= 31)) {
         if (!wino_ok(a)) return CDX_ENOTSUP;
         p.w = a->wpacked_wino;
-        return conv_dispatch_wino(experimental ? tile : 0, p, st);
-    }
-    if (t.wcfg == WCFG_SMALL || t.wcfg == WCFG_SMALL_VALU) return conv_dispatch_small(p, st, t.wcfg == WCFG_SMALL_VALU);
+        rc = conv_dispatch_wino(experimental ? tile : 0, p, st);
+    } else if (t.wcfg == WCFG_SMALL || t.wcfg == WCFG_SMALL_VALU) rc = conv_dispatch_small(p, st, t.wcfg == WCFG_SMALL_VALU);
 #ifdef CDX_TUNING
-    if (experimental) return conv_dispatch_exp(logtw, t.wcfg, p, st);
+    else if (experimental) rc = conv_dispatch_exp(logtw, t.wcfg, p, st);
 #endif
-    if (a->ksize == 1) return conv_dispatch_k1s1(logtw, t.wcfg, p, st);
-    if (a->stride == 1) return conv_dispatch_k3s1(logtw, t.wcfg, p, st);
-    return conv_dispatch_k3s2(logtw, t.wcfg, p, st);
+    else if (a->ksize == 1) rc = conv_dispatch_k1s1(logtw, t.wcfg, p, st);
+    else if (a->stride == 1) rc = conv_dispatch_k3s1(logtw, t.wcfg, p, st);
+    else rc = conv_dispatch_k3s2(logtw, t.wcfg, p, st);
+    // amax_out of the tile shapes without a fused maximum: one more pass over the (small: these are the sub-8-pixel levels
+    // and the layers a caller runs without the split image) output on the same stream
+    if (rc == CDX_OK && a->amax_out) rc = amax_launch(a->out, a->out_ld, a->batch, a->hout * a->wout, a->cout, a->amax_out, st);
+    return rc;
 }

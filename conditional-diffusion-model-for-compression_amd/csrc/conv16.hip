@@ -35,6 +35,8 @@ int validate(const cdx_conv_f16_args* a) {
     if (a->temb) CDX_REQUIRE(a->temb_ld >= a->cout);
     if (a->stats_out) CDX_REQUIRE(!a->out_is_f32);
     CDX_REQUIRE((int64_t)a->batch * a->hin * a->win < (1ll << 31) && (int64_t)a->batch * a->hout * a->wout < (1ll << 31));
+    // 32-bit byte offsets inside ONE image of a source (the kernel rebases its buffer resource per image)
+    CDX_REQUIRE((int64_t)a->hin * a->win * (a->c0 > a->c1 ? a->c0 : a->c1) * (a->src_is_f32 ? 4 : 2) < (1ll << 31));
     return CDX_OK;
 }
 
@@ -173,6 +175,9 @@ extern "C" int cdx_conv_f16(const cdx_conv_f16_args* a, void*, size_t, cdx_strea
     p.residual = a->residual;
     p.out = a->out; p.out_f32 = a->out_is_f32 ? 1 : 0; p.out_ld = a->out_ld; p.stats = a->stats_out;
     p.stats_wm = conv16_tail_2x2(a->cout, f16_mt(a)) ? 2 : 1;
+    p.act_exp = 0;
+    p.amax[0] = p.amax[1] = nullptr;
+    p.amax_out = nullptr;
     int logtw;
     tile_grid(a, logtw, p.tiles_x, p.tiles_y);
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));

@@ -82,7 +82,68 @@ struct Conv16Params {
     double* stats;
     int stats_wm;            // GroupNorm-sum slots per spatial tile (2 when the layer's last channel block runs the 2 x 2 layout)
     int tiles_x, tiles_y;
+    // SPLIT range contract (cdx.h): the activation exponent comes from act_exp (GroupNorm-ed input: gscale / gshift arrive
+    // pre-multiplied by 2^act_exp) or, per image, from the producers' amax words of the un-normalised sources
+    int act_exp;
+    const unsigned* amax[2]; // [B][CDX_AMAX_WORDS] float32 bit patterns (max over the words = max |x| of the image) per source, or null
+    unsigned* amax_out;      // [B][CDX_AMAX_WORDS] or null: atomic max of one word with the bit pattern of the wave's max |out|
 };
+
+// Activation scaling of one SPLIT workgroup (all wave-uniform: scalar registers).  Staged activations are x 2^ea with
+// max |x| 2^ea in [2^14, 2^15) (the weights sit in [2^13, 2^14) by the packer's 2^sw): hi = fp16(v), lo = fp16(v - hi) then
+// keep 22 significant bits for every element down to 2^-17 of the tensor's maximum and an ABSOLUTE error of 2^-39 of the
+// maximum below that -- float32-level error relative to the output scale at any input scale.  The accumulators hold
+// out 2^(sw + ea) =: out 2^S.
+struct ActScale {
+    float a;        // 2^ea
+    float ksilu;    // -log2(e) 2^-ea: SiLU of a pre-scaled value v2 = v 2^ea is v2 / (1 + exp2(v2 ksilu))
+    float un;       // 2^-S: accumulators -> outputs
+    float inv;      // 2^S: bias / temb / residual -> accumulator init
+    bool late;      // S > 64: inv times an O(1) additive term could overflow float32 -- bias / temb / residual are then added in
+                    // the epilogue (the accumulators start at 0); |S| is capped at 120 by giving up activation headroom
+};
+// max over the words of image b (b wave-uniform: one s_load_dwordx16 and scalar compares)
+using u32x16 = __attribute__((ext_vector_type(16))) unsigned;
+static_assert(CDX_AMAX_WORDS == 16, "amax_words reads one 64-byte row");
+__device__ __forceinline__ unsigned amax_words(const unsigned* base, int b) {
+    const u32x16 v = *reinterpret_cast<const u32x16*>(base + (size_t)b * CDX_AMAX_WORDS);
+    unsigned m = v[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) m = v[k] > m ? v[k] : m;
+    return m;
+}
+// one wave's contribution to amax_out: word chosen by `salt` (wave-global index).  The word only grows: most waves find a
+// larger value already there and skip the atomic; a stale read can only cause a redundant atomic, never a wrong maximum.
+__device__ __forceinline__ void amax_publish(unsigned* amax_out, int b, unsigned salt, float am) {
+    unsigned* w = amax_out + (size_t)b * CDX_AMAX_WORDS + (salt & (CDX_AMAX_WORDS - 1));
+    const unsigned bits = __float_as_uint(am);
+    if (bits > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, bits);
+}
+template <bool SPLIT, bool GN>
+__device__ __forceinline__ ActScale act_scale_of(const Conv16Params& p, int b) {
+    ActScale s{1.f, -1.44269504088896341f, 1.f, 1.f, false};
+    if constexpr (SPLIT) {
+        int ea = 0;
+        if constexpr (GN) ea = p.act_exp;
+        else if (p.amax[0]) {
+            unsigned m = amax_words(p.amax[0], b);
+            if (p.amax[1]) { const unsigned m1 = amax_words(p.amax[1], b); m = m1 > m ? m1 : m; }
+            const int E = (int)(m >> 23);
+            ea = (m == 0u || E >= 255) ? 0 : 141 - E;      // +-Inf / NaN bound, or an all-zero image: no scaling
+        }
+        ea = ea > 100 ? 100 : ea < -100 ? -100 : ea;
+        const int sw = 127 - (int)(__float_as_uint(p.wunscale) >> 23);
+        int S = sw + ea;
+        if (S > 120) { ea -= S - 120; S = 120; }
+        if (S < -120) { ea += -120 - S; S = -120; }
+        s.a = __uint_as_float((unsigned)(ea + 127) << 23);
+        s.ksilu = -1.44269504088896341f * __uint_as_float((unsigned)(127 - ea) << 23);
+        s.un = __uint_as_float((unsigned)(127 - S) << 23);
+        s.inv = __uint_as_float((unsigned)(127 + S) << 23);
+        s.late = S > 64;
+    }
+    return s;
+}
 
 // channels left for the last 128-channel block; the 2 x 2 wave layout serves it when they fit two N-tiles
 __host__ __device__ inline bool conv16_tail_2x2(int cout, int mt) { const int rem = cout % 128; return mt == 4 && rem > 0 && rem <= 64; }
@@ -118,8 +179,9 @@ struct Conv16Cfg {
     static_assert(GPC % PF == 0 || PF > GPC, "ring depth");
 };
 
-__device__ __forceinline__ float silu16_f(float v) {
-    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
+// SiLU of a value that carries a power-of-two scale: v2 = v 2^e, ksilu = -log2(e) 2^-e  ->  silu(v) 2^e
+__device__ __forceinline__ float silu16_f(float v2, float ksilu) {
+    return v2 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v2 * ksilu));
 }
 
 // STG (compile-time staging mode, chosen at launch from the GN / SiLU flags -- a runtime flag costs a v_cndmask per element
@@ -177,10 +239,11 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         }
     }
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+    const ActScale asc = act_scale_of<C::SPLIT != 0, kGN>(p, b);
 
     // ---- loader: thread -> (pixel slot pl of 64, channel octet q of 4) ----
     const int q = tid & 3, pl = tid >> 2;
-    int soff[NPASS];
+    int soff[NPASS];                                  // pixel index inside image b
     unsigned vmask = 0;
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
@@ -188,7 +251,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         const int hy = hp / C::HW, hx = hp - hy * C::HW;
         const int iy = iy0 + hy, ix = ix0 + hx;
         const bool ok = hp < C::NPIX && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-        soff[i] = ok ? ((b * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups)) : 0;
+        soff[i] = ok ? (iy >> p.ups) * p.Win + (ix >> p.ups) : 0;
         vmask |= ok ? (1u << i) : 0u;
     }
     float pre[NPASS][8];
@@ -198,18 +261,21 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     // Halo loads use buffer addressing: per-lane byte offset voff[i] = (pixel * channels + 8 q) * elem (one 32-bit VGPR per
     // pass, recomputed only when the chunk sequence moves from src0 to src1), scalar offset = chunk * 32 channels * elem.
     // hipcc's flat form spent ~25 VALU instructions of 64-bit address arithmetic per load (a 200-instruction clump per chunk).
-    // The resource is bounded to the tensor: a lane whose channel octet lies past the source's end (zero-filled at write
-    // time) may read past the last pixel -- such reads return 0 instead of faulting.
+    // The resource covers IMAGE b of the source only (the host checks that one image is below 2 GiB, so 32-bit offsets
+    // cannot wrap whatever the batch): padding pixels and channel octets past the source's end get the offset kOOB >= any
+    // resource size -- the hardware returns 0 for them, so un-normalised staging needs no select, and NaN / Inf of
+    // neighbouring data cannot leak into padding.
+    constexpr unsigned kOOB = 0x80000000u;
     unsigned voff[NPASS];
     __amdgpu_buffer_rsrc_t srs;
     int cur_src = -1;
     const unsigned esz = (C::SPLIT || p.src_f32) ? 4u : 2u;
     auto bind_source = [&](int sidx) {
         const unsigned cs = (unsigned)p.csrc[sidx];
-        const size_t bytes = (size_t)p.B * p.Hin * p.Win * cs * esz;
-        srs = buf_rsrc(p.src[sidx], bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes);
+        const size_t img = (size_t)p.Hin * p.Win * cs * esz;
+        srs = buf_rsrc(static_cast<const char*>(p.src[sidx]) + (size_t)b * img, (unsigned)img);
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) voff[i] = ((unsigned)soff[i] * cs + 8u * (unsigned)q) * esz;
+        for (int i = 0; i < NPASS; ++i) voff[i] = ((vmask >> i) & 1u) ? ((unsigned)soff[i] * cs + 8u * (unsigned)q) * esz : kOOB;
         cur_src = sidx;
     };
     auto issue_loads = [&](int chunk) {
@@ -225,8 +291,9 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             const bool hi = C::SPLIT || cl + 8 <= cs;
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) {
-                const f32x4 v0 = buf_load4(srs, voff[i], so);
-                const f32x4 v1 = buf_load4(srs, voff[i] + 16u, so);
+                const unsigned vo = cvalid ? voff[i] : kOOB;
+                const f32x4 v0 = buf_load4(srs, vo, so);
+                const f32x4 v1 = buf_load4(srs, vo + 16u, so);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     pre[i][e] = v0[e];
@@ -236,7 +303,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         } else {
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) {
-                const h8 v = __builtin_bit_cast(h8, buf_load4(srs, voff[i], so));
+                const h8 v = __builtin_bit_cast(h8, buf_load4(srs, cvalid ? voff[i] : kOOB, so));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pre[i][e] = (float)v[e];
             }
@@ -262,17 +329,18 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     unsigned uo[EPU / 2], uol[EPU / 2];               // the unit being computed: packed 16-bit pairs (hi | lo)
     auto unit_pair = [&](int u, int kp) {             // channels 2 kp, 2 kp + 1 of unit u
         const int i = u / UPP, e = EPU * (u % UPP) + 2 * kp;
+        // padding pixels / channels past the source were LOADED as 0 (kOOB); only GroupNorm's shift makes them non-zero again,
+        // and they must be zero AFTER the activation: one select per value there.  No clamp: NaN / Inf and values beyond the
+        // fp16 range (impossible for finite inputs under the range contract) propagate as non-finite outputs, as F.conv2d's do.
         const bool ok = cvalid && ((vmask >> i) & 1u);
-        // padding pixels / channels past the source are zero AFTER the activation: clamp bounds (0, 0) give that for free
-        // (one select per pair instead of one per value); real values saturate at the fp16 range instead of overflowing
-        const float bound = ok ? 65504.f : 0.f;
         float v[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             v[k] = pre[i][e + k];
             if constexpr (kGN) v[k] = fmaf(v[k], gsc[(e + k) >> 2][(e + k) & 3], gsh[(e + k) >> 2][(e + k) & 3]);
-            if constexpr (kSILU) v[k] = silu16_f(v[k]);
-            v[k] = __builtin_amdgcn_fmed3f(v[k], -bound, bound);
+            else if constexpr (C::SPLIT) v[k] *= asc.a;
+            if constexpr (kSILU) v[k] = silu16_f(v[k], asc.ksilu);
+            if constexpr (kGN) v[k] = ok ? v[k] : 0.f;
         }
         if constexpr (C::BF) {
             using b2 = __attribute__((ext_vector_type(2))) __bf16;
@@ -341,40 +409,45 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     // in SPLIT mode, the 16-bit storage type otherwise), 128 / 64 B per half wave.  (Tiles 4 pixels wide keep the epilogue
     // form: there 4 (lane >> 5) crosses tile rows.)
     constexpr bool kAccInit = C::SPLIT || C::LOGTW >= 3;
-    if constexpr (kAccInit) {
+    // acc = acc * macc + (bias + temb + residual) * inv.  At the start (acc = 0, FIRST): the init; SPLIT tiles whose scale 2^S
+    // could overflow the product (asc.late) run it at the end instead with macc = 2^-S, inv = 1.
+    auto add_terms = [&](auto first_, float macc, float inv) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_)::value;
         const int n = ntile * 32 + li;
-        if (nvalid && n < p.Cout) {
-            const float inv = C::SPLIT ? 1.0f / p.wunscale : 1.0f;
-            float add = p.bias ? p.bias[n] : 0.f;
-            if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
-            add *= inv;
-            if (p.residual && !(C::ABL & 16)) {
-                // rows past the image end / columns past the row end read other (or no: bounded resource) pixels; those
-                // accumulators are never stored
-                constexpr unsigned es = C::SPLIT ? 4u : 2u;
-                const size_t first = (((size_t)b * p.Hout + oy0w) * p.Wout + ox0) * p.Cout;
-                const size_t left = ((size_t)p.B * p.Hout * p.Wout * p.Cout - first) * es;
-                const __amdgpu_buffer_rsrc_t rr = buf_rsrc(static_cast<const char*>(p.residual) + first * es,
-                                                           left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)left);
-                const unsigned voff = ((unsigned)(4 * lh) * (unsigned)p.Cout + (unsigned)n) * es;
+        if (!(nvalid && n < p.Cout)) return;
+        float add = p.bias ? p.bias[n] : 0.f;
+        if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
+        add *= inv;
+        if (p.residual && !(C::ABL & 16)) {
+            // rows past the image end / columns past the row end read other (or no: bounded resource) pixels; those
+            // accumulators are never stored
+            constexpr unsigned es = C::SPLIT ? 4u : 2u;
+            const size_t first = (((size_t)b * p.Hout + oy0w) * p.Wout + ox0) * p.Cout;
+            const size_t left = ((size_t)p.B * p.Hout * p.Wout * p.Cout - first) * es;
+            const __amdgpu_buffer_rsrc_t rr = buf_rsrc(static_cast<const char*>(p.residual) + first * es,
+                                                       left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)left);
+            const unsigned voff = ((unsigned)(4 * lh) * (unsigned)p.Cout + (unsigned)n) * es;
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
+            for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int mb = t * 32 + 8 * (r >> 2) + (r & 3);
-                        const unsigned pix = (unsigned)(mb >> C::LOGTW) * (unsigned)p.Wout + (unsigned)(mb & (C::TW - 1));
-                        float rv;
-                        if constexpr (C::SPLIT) rv = buf_load1(rr, voff, pix * (unsigned)p.Cout * es);
-                        else rv = (float)__builtin_bit_cast(H, __builtin_amdgcn_raw_buffer_load_b16(rr, voff, pix * (unsigned)p.Cout * es, 0));
-                        acc[t][r] = fmaf(rv, inv, add);
-                    }
-            } else {
+                for (int r = 0; r < 16; ++r) {
+                    const int mb = t * 32 + 8 * (r >> 2) + (r & 3);
+                    const unsigned pix = (unsigned)(mb >> C::LOGTW) * (unsigned)p.Wout + (unsigned)(mb & (C::TW - 1));
+                    float rv;
+                    if constexpr (C::SPLIT) rv = buf_load1(rr, voff, pix * (unsigned)p.Cout * es);
+                    else rv = (float)__builtin_bit_cast(H, __builtin_amdgcn_raw_buffer_load_b16(rr, voff, pix * (unsigned)p.Cout * es, 0));
+                    const float t_ = fmaf(rv, inv, add);
+                    acc[t][r] = FIRST ? t_ : fmaf(acc[t][r], macc, t_);
+                }
+        } else {
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
+            for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[t][r] = add;
-            }
+                for (int r = 0; r < 16; ++r) acc[t][r] = FIRST ? add : fmaf(acc[t][r], macc, add);
         }
+    };
+    if constexpr (kAccInit) {
+        if (!asc.late) add_terms(std::true_type{}, 1.f, asc.inv);
     }
 
     h8 ring[PF][C::PLANES];
@@ -511,9 +584,15 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         constexpr unsigned kDrop = 0x80000000u;                                    // beyond any resource: the store is dropped
         const __amdgpu_buffer_rsrc_t ors = buf_rsrc(static_cast<float*>(p.out) + first, left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)left);
         const unsigned vbase = nok ? ((unsigned)(4 * lh) * (unsigned)p.out_ld + (unsigned)n) * 4u : kDrop;
-        const float un = p.wunscale;
-        const bool want_stats = p.stats && !(C::ABL & 32);
+        float un = asc.un;
+        if (asc.late) {                              // (rare: see ActScale) outputs first, then the additive terms at their own scale
+            add_terms(std::false_type{}, un, 1.f);   // (lanes without an output channel keep raw accumulators: never stored)
+            un = 1.f;
+        }
+        // (the sums variant also serves amax_out: a caller that wants only one of them pays for both)
+        const bool want_stats = (p.stats || p.amax_out) && !(C::ABL & 32);
         double s1 = 0, s2 = 0;
+        float am = 0.f;
         auto direct = [&](auto full_, auto has_stats) __attribute__((always_inline)) {
 #pragma unroll
             for (int t = 0; t < MT; ++t)
@@ -526,9 +605,11 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                     bool ok = true;
                     if constexpr (!decltype(full_)::value) ok = oy0w + row < p.Hout && ox0 + col + 4 * lh < p.Wout;
                     if constexpr (decltype(has_stats)::value) {
-                        const double d = ok ? (double)x : 0.0;
+                        const float xs = ok ? x : 0.f;
+                        const double d = (double)xs;
                         s1 += d;
                         s2 = fma(d, d, s2);
+                        am = fmaxf(am, fabsf(xs));                      // (NaN skipped, Inf kept)
                     }
                     buf_store1(ors, ok ? vbase : kDrop, soff, x);       // (last use of x: the tie in buf_store1 then costs no copy)
                 }
@@ -538,7 +619,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         if (full) { if (want_stats) direct(T_{}, T_{}); else direct(T_{}, F_{}); }
         else      { if (want_stats) direct(F_{}, T_{}); else direct(F_{}, F_{}); }
         stamp(12);
-        if (want_stats) {
+        if (p.stats && !(C::ABL & 32)) {
             s1 += __shfl_xor(s1, 32);                  // the two lane halves hold different pixels of the same channel
             s2 += __shfl_xor(s2, 32);
             if (lh == 0 && nok) {
@@ -547,7 +628,17 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                 double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + n) * 2;
                 o[0] = s1;
                 o[1] = s2;
+                if (WM == 1 && p.stats_wm == 2) {      // a 1 x 4 block of a layer whose LAST block runs 2 x 2: second slot = 0
+                    o[(size_t)p.Cout * 2] = 0.0;
+                    o[(size_t)p.Cout * 2 + 1] = 0.0;
+                }
             }
+        }
+        if (p.amax_out && !(C::ABL & 32)) {
+            if (!nok) am = 0.f;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) am = fmaxf(am, __shfl_xor(am, off));
+            if (lane == 0) amax_publish(p.amax_out, b, (blockIdx.x * 4 + wv) * 5 + blockIdx.y, am);
         }
         return;
     }
@@ -611,6 +702,10 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                     double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + n) * 2;
                     o[0] = s1;
                     o[1] = s2;
+                    if (WM == 1 && p.stats_wm == 2) {
+                        o[(size_t)p.Cout * 2] = 0.0;
+                        o[(size_t)p.Cout * 2 + 1] = 0.0;
+                    }
                 }
             }
             return;
@@ -698,8 +793,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             s2[c] += __shfl_xor(s2[c], 32);
         }
         if (lh == 0 && q4 == 0 && quad_ok) {
-            // p.stats_wm slots per tile: a layer with a 2 x 2 last block has two (its 1 x 4 blocks fill the first, the
-            // second stays zero as allocated)
+            // p.stats_wm slots per tile: a layer with a 2 x 2 last block has two (its 1 x 4 blocks fill the first and zero the second)
             const int slot = (ty * p.tiles_x + tx) * p.stats_wm + (WM == 2 ? wm : 0);
             const int nslots = p.tiles_y * p.tiles_x * p.stats_wm;
 #pragma unroll
@@ -708,6 +802,10 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                     double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + cq + c) * 2;
                     o[0] = s1[c];
                     o[1] = s2[c];
+                    if (WM == 1 && p.stats_wm == 2) {
+                        o[(size_t)p.Cout * 2] = 0.0;
+                        o[(size_t)p.Cout * 2 + 1] = 0.0;
+                    }
                 }
             }
         }

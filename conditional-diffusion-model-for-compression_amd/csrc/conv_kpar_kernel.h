@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
 
     // ---- loader (per wave): lane -> (pixel slot pl of 16, channel octet q of 4) ----
     const int q = lane & 3, pl = lane >> 2;
-    int soff[NPASS];
+    int soff[NPASS];                                               // pixel index inside image b
     unsigned vmask = 0;
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
@@ -73,21 +73,24 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
         const int hy = hp / C::HW, hx = hp - hy * C::HW;
         const int iy = iy0 + hy, ix = ix0 + hx;
         const bool ok = hp < C::NPIX && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-        soff[i] = ok ? ((b * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups)) : 0;
+        soff[i] = ok ? (iy >> p.ups) * p.Win + (ix >> p.ups) : 0;
         vmask |= ok ? (1u << i) : 0u;
     }
+    const ActScale asc = act_scale_of<C::SPLIT != 0, kGN>(p, b);
     float pre[NPASS][8];
     f32x4 gsc[2], gsh[2];
     bool cvalid = false;
+    // per-image buffer resource; padding pixels / channel octets past the source's end load as 0 (offset kOOB): conv16_kernel.h
+    constexpr unsigned kOOB = 0x80000000u;
     unsigned voff[NPASS];
     __amdgpu_buffer_rsrc_t srs;
     int cur_src = -1;
     auto bind_source = [&](int sidx) {
         const unsigned cs = (unsigned)p.csrc[sidx];
-        const size_t bytes = (size_t)p.B * p.Hin * p.Win * cs * ES;
-        srs = buf_rsrc(p.src[sidx], bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes);
+        const size_t img = (size_t)p.Hin * p.Win * cs * ES;
+        srs = buf_rsrc(static_cast<const char*>(p.src[sidx]) + (size_t)b * img, (unsigned)img);
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) voff[i] = ((unsigned)soff[i] * cs + 8u * (unsigned)q) * ES;
+        for (int i = 0; i < NPASS; ++i) voff[i] = ((vmask >> i) & 1u) ? ((unsigned)soff[i] * cs + 8u * (unsigned)q) * ES : kOOB;
         cur_src = sidx;
     };
     auto issue_loads = [&](int chunk) {
@@ -99,15 +102,16 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
         const unsigned so = (unsigned)cc * (unsigned)KC * ES;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
+            const unsigned vo = cvalid ? voff[i] : kOOB;
             if constexpr (C::SPLIT) {
-                const f32x4 v0 = buf_load4(srs, voff[i], so), v1 = buf_load4(srs, voff[i] + 16u, so);
+                const f32x4 v0 = buf_load4(srs, vo, so), v1 = buf_load4(srs, vo + 16u, so);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     pre[i][e] = v0[e];
                     pre[i][4 + e] = v1[e];
                 }
             } else {
-                const h8 v = __builtin_bit_cast(h8, buf_load4(srs, voff[i], so));
+                const h8 v = __builtin_bit_cast(h8, buf_load4(srs, vo, so));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pre[i][e] = (float)v[e];
             }
@@ -125,8 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
     auto stage_pass = [&](int i) {                                 // GroupNorm / SiLU / saturate / split, one pixel slot x 8 channels
         const int hp = i * 16 + pl;
         const int hy = hp / C::HW, hx = hp - hy * C::HW;
-        const bool ok = cvalid && ((vmask >> i) & 1u);
-        const float bound = ok ? 65504.f : 0.f;                    // clamp bounds (0, 0) zero the padding after the activation
+        const bool ok = cvalid && ((vmask >> i) & 1u);            // (padding loads as 0: only GroupNorm's shift needs the select)
         using u4 = __attribute__((ext_vector_type(4))) unsigned;
         u4 o, ol;
 #pragma unroll
@@ -136,8 +139,9 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
             for (int k = 0; k < 2; ++k) {
                 v[k] = pre[i][e + k];
                 if constexpr (kGN) v[k] = fmaf(v[k], gsc[(e + k) >> 2][(e + k) & 3], gsh[(e + k) >> 2][(e + k) & 3]);
-                if constexpr (kSILU) v[k] = silu16_f(v[k]);
-                v[k] = __builtin_amdgcn_fmed3f(v[k], -bound, bound);
+                else if constexpr (C::SPLIT) v[k] *= asc.a;
+                if constexpr (kSILU) v[k] = silu16_f(v[k], asc.ksilu);
+                if constexpr (kGN) v[k] = ok ? v[k] : 0.f;
             }
             if constexpr (C::BF) {
                 using b2 = __attribute__((ext_vector_type(2))) __bf16;
@@ -174,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int n = ntile * 32 + li;
-    if (wv == 0 && n < p.Cout) {                                   // bias + temb + residual through wave 0's accumulator init
-        const float inv = C::SPLIT ? 1.0f / p.wunscale : 1.0f;
+    if (wv == 0 && n < p.Cout && !asc.late) {                      // bias + temb + residual through wave 0's accumulator init
+        const float inv = asc.inv;
         float add = p.bias ? p.bias[n] : 0.f;
         if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
         add *= inv;
@@ -258,8 +262,9 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
     const int q4 = li & 3;
     const int cq = ntile * 32 + (li & ~3);
     const bool quad_ok = cq < p.Cout;
-    const float un = C::SPLIT ? p.wunscale : 1.0f;
+    const float un = asc.un;
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    float am = 0.f;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         float x[4];
@@ -276,17 +281,35 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
         const int oy = oy0 + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
         if (quad_ok && oy < p.Hout && ox < p.Wout) {
             const size_t pix = ((size_t)b * p.Hout + oy) * p.Wout + ox;
-            if constexpr (C::SPLIT) *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + pix * p.out_ld + cq) = f32x4{x[0], x[1], x[2], x[3]};
-            else *reinterpret_cast<h4*>(static_cast<H*>(p.out) + pix * p.out_ld + cq) = h4{(H)x[0], (H)x[1], (H)x[2], (H)x[3]};
-            if (p.stats) {
+            if (asc.late) {                                        // (SPLIT, rare: ActScale) additive terms at their own scale
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const double d = (double)x[c];
+                    if (cq + c < p.Cout) {
+                        float add = p.bias ? p.bias[cq + c] : 0.f;
+                        if (p.temb) add += p.temb[(size_t)b * p.temb_ld + cq + c];
+                        if (p.residual) add += static_cast<const float*>(p.residual)[pix * p.Cout + cq + c];
+                        x[c] += add;
+                    }
+                }
+            }
+            if constexpr (C::SPLIT) *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + pix * p.out_ld + cq) = f32x4{x[0], x[1], x[2], x[3]};
+            else *reinterpret_cast<h4*>(static_cast<H*>(p.out) + pix * p.out_ld + cq) = h4{(H)x[0], (H)x[1], (H)x[2], (H)x[3]};
+            if (p.stats || p.amax_out) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float xs = cq + c < p.Cout ? x[c] : 0.f;
+                    const double d = (double)xs;
                     s1[c] += d;
                     s2[c] = fma(d, d, s2[c]);
+                    am = fmaxf(am, fabsf(xs));
                 }
             }
         }
+    }
+    if (p.amax_out) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) am = fmaxf(am, __shfl_xor(am, off));
+        if (lane == 0) amax_publish(p.amax_out, b, (blockIdx.x * 4 + wv) * 5 + blockIdx.y, am);
     }
     if (p.stats) {
 #pragma unroll

@@ -66,20 +66,26 @@ namespace cdx {
 // Is this cdx_conv_f32 launch one the SPLIT kernel is built for?  (conv.hip asks before choosing the tile.)
 bool conv_split_ok(const cdx_conv_args* a) {
     if (!a->wpacked_split || !aligned16(a->wpacked_split) || !(a->wsplit_unscale > 0.f)) return false;
+    // RANGE CONTRACT (cdx.h): the staged activations need a power-of-two exponent -- static for GroupNorm-ed inputs (gn_exp),
+    // per image from the producers' amax words otherwise.  A launch that brings neither runs on the f32-input MFMA kernels.
+    if (!(a->flags & CDX_CONV_GN) && (!a->src_amax0 || (a->c1 > 0 && !a->src_amax1))) return false;
     // (below 8 pixels wide the f32-MFMA split-K tiles stay)
     if (a->wout < 8 || a->cout <= 4) return false;
     if (a->stride == 2 && a->wout < 16) return false;
-    if ((a->c0 % 8) != 0 || (a->c1 % 8) != 0) return false;                           // the loader moves 8-channel octets                                   // (8^2 and below: f32-MFMA split-K tiles)
+    if ((a->c0 % 8) != 0 || (a->c1 % 8) != 0) return false;                           // the loader moves 8-channel octets
     if (a->stride == 2 && a->ksize != 3) return false;
     if ((a->out_ld % 4) != 0 || a->out_ld < ((a->cout + 3) & ~3)) return false;      // outputs move as 4-channel vectors
     if ((a->residual || a->stats_out) && (a->cout % 4) != 0) return false;
+    // 32-bit byte offsets inside ONE image of a source (the kernel rebases its buffer resource per image)
+    const int cmax = a->c0 > a->c1 ? a->c0 : a->c1;
+    if ((int64_t)a->hin * a->win * cmax * 4 >= (1ll << 31)) return false;
     return true;
 }
 
 // GroupNorm-sum slots per spatial tile of a SPLIT launch: 2 when the 128-pixel tile's last channel block runs 2 x 2
 int conv_split_slots_per_tile(const cdx_conv_args* a) {
     if (a->stride == 1 && a->wout < 16) return 4;      // chunk-parallel tile (conv_kpar_kernel.h): one slot per finishing wave
-    return conv16_tail_2x2(a->cout, a->stride == 2 ? 2 : 4) ? 2 : 1;
+    return conv16_tail_2x2(a->cout, (a->stride == 2 || a->wout < 32) ? 2 : 4) ? 2 : 1;
 }
 
 int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
@@ -103,6 +109,10 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     p.residual = a->residual;
     p.out = a->out; p.out_f32 = 1; p.out_ld = a->out_ld; p.stats = a->stats_out;
     p.stats_wm = conv_split_slots_per_tile(a);
+    p.act_exp = (a->flags & CDX_CONV_GN) ? a->gn_exp : 0;
+    p.amax[0] = (a->flags & CDX_CONV_GN) ? nullptr : a->src_amax0;
+    p.amax[1] = (a->flags & CDX_CONV_GN) || a->c1 == 0 ? nullptr : a->src_amax1;
+    p.amax_out = a->amax_out;
     // tile: 128 pixels x 128 channels at >= 32 pixels wide; 64 x 128 for stride 2 and at 16 pixels wide; 64 pixels x 32
     // channels with the input chunks split over the waves at 8 pixels wide (conv_kpar_kernel.h: at batch 16 that level has
     // too few output pixels to fill 256 CUs with 128-channel tiles: 1.06 -> 0.49 ms per forward for its 3x3 layers)

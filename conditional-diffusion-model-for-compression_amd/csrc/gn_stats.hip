@@ -9,6 +9,8 @@
 //   gn_finalize: one wave per (batch, group): sums the partials in float64, mean / rstd, then
 //                scale = rstd*gamma, shift = beta - mean*scale in float32 (F.group_norm's own form).
 // No reference file exists to cite (reference snapshot is empty); semantics = torch F.group_norm.
+#include <math.h>
+
 #include "common.h"
 
 using namespace cdx;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(64) void gn_finalize(const double* __restrict__ par
                                                   int hw, float eps, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, float* __restrict__ scale,
                                                   float* __restrict__ shift, float* __restrict__ mean_out,
-                                                  float* __restrict__ rstd_out) {
+                                                  float* __restrict__ rstd_out, float oscale) {
     const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int cpg = ctot / groups;
     const int items = nsplit * cpg;
@@ -106,8 +108,8 @@ __global__ __launch_bounds__(64) void gn_finalize(const double* __restrict__ par
     for (int k = lane; k < cpg; k += 64) {
         const int c = g * cpg + k;
         const float sc = rstdf * gamma[c];
-        scale[(size_t)b * ctot + c] = sc;
-        shift[(size_t)b * ctot + c] = -sc * meanf + beta[c];
+        scale[(size_t)b * ctot + c] = sc * oscale;                       // (oscale = 2^out_exp: exact)
+        shift[(size_t)b * ctot + c] = (-sc * meanf + beta[c]) * oscale;
     }
 }
 
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void gn_finalize2(const double* __restrict__ p
                                                     int hw, float eps, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, float* __restrict__ scale,
                                                     float* __restrict__ shift, float* __restrict__ mean_out,
-                                                    float* __restrict__ rstd_out) {
+                                                    float* __restrict__ rstd_out, float oscale) {
     __shared__ double red[2][256];
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int ctot = c0 + c1, cpg = ctot / groups;
@@ -167,8 +169,8 @@ __global__ __launch_bounds__(256) void gn_finalize2(const double* __restrict__ p
     for (int k = tid; k < cpg; k += 256) {
         const int c = cbeg + k;
         const float sc = rstdf * gamma[c];
-        scale[(size_t)b * ctot + c] = sc;
-        shift[(size_t)b * ctot + c] = -sc * meanf + beta[c];
+        scale[(size_t)b * ctot + c] = sc * oscale;                       // (oscale = 2^out_exp: exact)
+        shift[(size_t)b * ctot + c] = (-sc * meanf + beta[c]) * oscale;
     }
 }
 
@@ -182,9 +184,10 @@ extern "C" int cdx_gn_finalize_f32(const cdx_gn_finalize_args* a, void*, size_t,
     CDX_REQUIRE((a->c1 == 0) == (a->part1 == nullptr));
     if (a->c1) CDX_REQUIRE(a->slots1 > 0);
     CDX_REQUIRE(a->batch > 0 && a->batch <= 65535 && a->hw > 0 && a->groups > 0 && (a->c0 + a->c1) % a->groups == 0);
+    CDX_REQUIRE(a->out_exp >= -60 && a->out_exp <= 60);
     hipLaunchKernelGGL(gn_finalize2, dim3(a->groups, a->batch), dim3(256), 0, static_cast<hipStream_t>(stream), a->part0,
                        a->slots0, a->c0, a->part1, a->slots1, a->c1, a->groups, a->hw, a->eps, a->gamma, a->beta, a->scale,
-                       a->shift, a->mean, a->rstd);
+                       a->shift, a->mean, a->rstd, ldexpf(1.f, a->out_exp));
     return check_launch();
 }
 
@@ -198,6 +201,7 @@ extern "C" int cdx_gn_stats_f32(const cdx_gn_stats_args* a, void* ws, size_t ws_
     CDX_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c0 % 4) == 0 && (a->c1 % 4) == 0);
     CDX_REQUIRE((a->c1 == 0) == (a->src1 == nullptr));
     CDX_REQUIRE(a->batch > 0 && a->batch <= 65535 && a->hw > 0 && a->groups > 0);
+    CDX_REQUIRE(a->out_exp >= -60 && a->out_exp <= 60);
     const int ctot = a->c0 + a->c1;
     CDX_REQUIRE(ctot % a->groups == 0);
     CDX_REQUIRE(aligned16(a->src0) && aligned16(a->src1) && aligned16(ws));
@@ -214,6 +218,6 @@ extern "C" int cdx_gn_stats_f32(const cdx_gn_stats_args* a, void* ws, size_t ws_
         if ((rc = check_launch())) return rc;
     }
     hipLaunchKernelGGL(gn_finalize, dim3(a->groups, a->batch), dim3(64), 0, st, part, nsplit, ctot, a->groups, a->hw,
-                       a->eps, a->gamma, a->beta, a->scale, a->shift, a->mean, a->rstd);
+                       a->eps, a->gamma, a->beta, a->scale, a->shift, a->mean, a->rstd, ldexpf(1.f, a->out_exp));
     return check_launch();
 }

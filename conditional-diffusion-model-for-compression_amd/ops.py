@@ -111,7 +111,7 @@ def conv16_stats_buffer(a: _abi.ConvF16Args, device) -> torch.Tensor:
     slots = _abi.lib().cdx_conv_f16_stats_slots(ctypes.byref(a))
     if slots <= 0:
         raise _abi.CdxError("cdx_conv_f16_stats_slots: bad arguments")
-    buf = torch.zeros(a.batch, slots, a.cout, 2, dtype=torch.float64, device=device)
+    buf = torch.full((a.batch, slots, a.cout, 2), float("nan"), dtype=torch.float64, device=device)     # (as conv_stats_buffer)
     a.stats_out = buf.data_ptr()
     return buf
 
@@ -130,7 +130,12 @@ def conv16(pc: PackedConv16, src0, src1=None, *, out_dtype=None, want_stats=Fals
 
 
 def conv_args(pc: PackedConv, src0, src1, out, *, stride=1, upsample=False, gn=None, silu=False,
-              temb=None, temb_off=0, temb_ld=0, residual=None, out_ld=None, stats=None) -> _abi.ConvArgs:
+              temb=None, temb_off=0, temb_ld=0, residual=None, out_ld=None, stats=None,
+              src_amax=None, amax_out=None) -> _abi.ConvArgs:
+    """gn = (scale, shift) or (scale, shift, exp): exp = the out_exp the GroupNorm launch wrote them with (cdx.h gn_exp).
+    src_amax = (amax0, amax1 | None): int32 [B, CDX_AMAX_WORDS] tensors (amax_buffer) with the float32 bit patterns of
+    max |x| per image of the sources (cdx.h RANGE CONTRACT: an un-normalised launch takes the split-fp16 tile only with
+    them); amax_out: such a tensor for the output."""
     B, hin, win, c0 = src0.shape
     assert c0 == pc.c0 and (src1 is None) == (pc.c1 == 0)
     if src1 is not None:
@@ -148,6 +153,11 @@ def conv_args(pc: PackedConv, src0, src1, out, *, stride=1, upsample=False, gn=N
     a.wpacked_split, a.wsplit_unscale = _ptr(pc.w_split), pc.split_unscale
     if gn is not None:
         a.gn_scale, a.gn_shift = _ptr(gn[0]), _ptr(gn[1])
+        a.gn_exp = int(gn[2]) if len(gn) > 2 else 0
+    if src_amax is not None:
+        a.src_amax0 = _ptr(src_amax[0])
+        a.src_amax1 = _ptr(src_amax[1]) if len(src_amax) > 1 else None
+    a.amax_out = _ptr(amax_out)
     if temb is not None:
         a.temb, a.temb_ld = _ptr(temb, 4 * temb_off), temb_ld or temb.shape[-1]
     a.residual = _ptr(residual)
@@ -155,7 +165,7 @@ def conv_args(pc: PackedConv, src0, src1, out, *, stride=1, upsample=False, gn=N
     assert out.shape[0] == B and out.shape[1] == hout and out.shape[2] == wout and a.out_ld >= pc.cout
     if stats is not None:          # float64 [B, slots, cout, 2] partial sums for gn_finalize (see conv_stats_buffer)
         assert stats.dtype == torch.float64 and stats.is_contiguous()
-        a.stats_out = stats.data_ptr()
+        a.stats_out, a.stats_slots = stats.data_ptr(), stats.shape[1]
     return a
 
 
@@ -165,12 +175,13 @@ def conv_stats_buffer(a: _abi.ConvArgs, device) -> torch.Tensor:
     slots = _abi.lib().cdx_conv_stats_slots(ctypes.byref(a))
     if slots <= 0:
         raise _abi.CdxError("cdx_conv_stats_slots: bad arguments")
-    buf = torch.zeros(a.batch, slots, a.cout, 2, dtype=torch.float64, device=device)
-    a.stats_out = buf.data_ptr()
+    # every entry is written by the launch (cdx.h): NaN-filled so that a slot a kernel skipped cannot pass for a zero sum
+    buf = torch.full((a.batch, slots, a.cout, 2), float("nan"), dtype=torch.float64, device=device)
+    a.stats_out, a.stats_slots = buf.data_ptr(), slots
     return buf
 
 
-def gn_finalize_args(stats0, stats1, hw, gamma, beta, groups, scale, shift, eps=1e-5, mean=None, rstd=None):
+def gn_finalize_args(stats0, stats1, hw, gamma, beta, groups, scale, shift, eps=1e-5, mean=None, rstd=None, out_exp=0):
     a = _abi.GnFinalizeArgs()
     a.part0, a.slots0, a.c0 = stats0.data_ptr(), stats0.shape[1], stats0.shape[2]
     if stats1 is not None:
@@ -178,6 +189,7 @@ def gn_finalize_args(stats0, stats1, hw, gamma, beta, groups, scale, shift, eps=
     a.batch, a.hw, a.groups, a.eps = stats0.shape[0], hw, groups, eps
     a.gamma, a.beta, a.scale, a.shift = _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift)
     a.mean, a.rstd = _ptr(mean), _ptr(rstd)
+    a.out_exp = out_exp
     return a
 
 
@@ -193,28 +205,88 @@ def gn_finalize(stats0, stats1, hw, gamma, beta, groups, eps=1e-5, want_moments=
     return (scale, shift, mean, rstd) if want_moments else (scale, shift)
 
 
+def amax_buffer(batch: int, device) -> torch.Tensor:
+    """Zeroed int32 [B, CDX_AMAX_WORDS] amax words (cdx.h src_amax0/1, amax_out; 64-byte aligned rows)."""
+    return torch.zeros(batch, _abi.AMAX_WORDS, dtype=torch.int32, device=device)
+
+
+def amax_value(words: torch.Tensor) -> torch.Tensor:
+    """float32 [B] = max |x| per image from its amax words."""
+    return words.view(torch.float32).amax(dim=-1)
+
+
+def amax(x, channels: int | None = None, out=None):
+    """int32 [B, CDX_AMAX_WORDS]: float32 bit patterns whose maximum per image is max |x[b]| over channels [0, channels)
+    (cdx_amax_f32; max-combines into `out`)."""
+    B, ld = x.shape[0], x.shape[-1]
+    if out is None:
+        out = amax_buffer(B, x.device)
+    a = _abi.AmaxArgs(_ptr(x), ld, B, x.numel() // (B * ld), channels or ld, _ptr(out))
+    _call("amax_f32", a, None, 0, x)
+    return out
+
+
+def check_finite(x, channels: int | None = None, limit: float = 0.0) -> int:
+    """Debug: status word of cdx_check_finite_f32 over channels [0, channels) of an NHWC float32 tensor (syncs)."""
+    ld = x.shape[-1]
+    status = torch.zeros(1, dtype=torch.int32, device=x.device)
+    a = _abi.CheckFiniteArgs(_ptr(x), ld, x.numel() // ld, channels or ld, limit, _ptr(status))
+    _call("check_finite_f32", a, None, 0, x)
+    return int(status.item())
+
+
 def conv(pc: PackedConv, src0, src1=None, **kw):
-    """out = conv(silu(gn(cat[src0, src1]))) + bias (+ temb) (+ residual); NHWC in, NHWC out."""
+    """out = conv(silu(gn(cat[src0, src1]))) + bias (+ temb) (+ residual); NHWC in, NHWC out.
+
+    Range (cdx.h RANGE CONTRACT): an un-normalised launch gets the per-image maxima of its sources from one cdx_amax_f32
+    pass per source here (the UNet takes them from the producing launches instead) unless `src_amax` is given or
+    auto_range=False; a GroupNorm-ed launch takes its exponent from gn = (scale, shift, exp) (see gn_stats(act_exp=...)).
+    debug=True: run cdx_check_finite_f32 over the output and raise on NaN / Inf."""
     B, hin, win, _ = src0.shape
     up, stride = kw.get("upsample", False), kw.get("stride", 1)
     hv, wv = (hin * 2, win * 2) if up else (hin, win)
     hout, wout = (hv, wv) if stride == 1 else ((hv + 1) // 2, (wv + 1) // 2)
     out = kw.pop("out", None)
     tile = kw.pop("tile", -1)        # diagnostics: force a tile shape (cdx.h CDX_TILE_*)
+    debug = kw.pop("debug", False)
+    auto_range = kw.pop("auto_range", True)
     if out is None:
         out = torch.empty(B, hout, wout, kw.get("out_ld") or pc.cout, device=src0.device, dtype=torch.float32)
         if out.shape[-1] != pc.cout:
             out.zero_()
     want_stats = kw.pop("want_stats", False)
+    want_amax = kw.pop("want_amax", False)
+    if want_amax:
+        kw["amax_out"] = amax_buffer(B, src0.device)
+    gn_affine = kw.pop("gn_affine", None)     # (gamma, beta, groups): GroupNorm computed here, with the exponent the tile wants
+    import ctypes
+    if gn_affine is not None:
+        gamma, beta, groups = gn_affine
+        C = src0.shape[-1] + (0 if src1 is None else src1.shape[-1])
+        sc, sh = torch.empty(B, C, device=src0.device), torch.empty(B, C, device=src0.device)
+        e = gn_act_exp(gamma, beta, groups, hin * win) if pc.w_split is not None else 0
+        probe = conv_args(pc, src0, src1, out, gn=(sc, sh, e), **{k: v for k, v in kw.items() if k != "gn"})
+        split = tile == _abi.TILE_SPLIT or (tile < 0 and _abi.lib().cdx_conv_select_tile(ctypes.byref(probe)) == _abi.TILE_SPLIT)
+        e = e if split else 0
+        ga = gn_stats_args(src0, src1, gamma, beta, groups, sc, sh, out_exp=e)
+        wp, wb, keep = _ws(_abi.workspace_bytes("gn_stats_f32", ga), src0.device)
+        _call("gn_stats_f32", ga, wp, wb, src0)
+        kw["gn"] = (sc, sh, e)
+    if auto_range and kw.get("gn") is None and kw.get("src_amax") is None and pc.w_split is not None:
+        kw["src_amax"] = (amax(src0),) + ((amax(src1),) if src1 is not None else ())
     a = conv_args(pc, src0, src1, out, **kw)
     stats = conv_stats_buffer(a, src0.device) if want_stats else None
-    import ctypes
     with torch.cuda.device(src0.device):
         _abi.check(_abi.lib().cdx_conv_f32_tile(ctypes.byref(a), tile, None, 0, _stream(src0)), "cdx_conv_f32_tile")
-    return (out, stats) if want_stats else out
+    if debug:
+        st = check_finite(out, pc.cout)
+        if st:
+            raise _abi.CdxError(f"conv (debug): output holds non-finite values (status {st})")
+    res = (out,) + ((stats,) if want_stats else ()) + ((kw["amax_out"],) if want_amax else ())
+    return res if len(res) > 1 else out
 
 
-def gn_stats_args(src0, src1, gamma, beta, groups, scale, shift, eps=1e-5, mean=None, rstd=None) -> _abi.GnStatsArgs:
+def gn_stats_args(src0, src1, gamma, beta, groups, scale, shift, eps=1e-5, mean=None, rstd=None, out_exp=0) -> _abi.GnStatsArgs:
     B = src0.shape[0]
     c0 = src0.shape[-1]
     hw = src0.numel() // (B * c0)
@@ -223,11 +295,19 @@ def gn_stats_args(src0, src1, gamma, beta, groups, scale, shift, eps=1e-5, mean=
     a.batch, a.hw, a.groups, a.eps = B, hw, groups, eps
     a.gamma, a.beta, a.scale, a.shift = _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift)
     a.mean, a.rstd = _ptr(mean), _ptr(rstd)
+    a.out_exp = out_exp
     return a
 
 
-def gn_stats(src0, src1, gamma, beta, groups, eps=1e-5, want_moments=False):
-    """(scale[B,C], shift[B,C]) such that group_norm(x)[b,...,c] = x*scale[b,c] + shift[b,c]."""
+def gn_act_exp(gamma, beta, groups: int, hw: int) -> int:
+    """The static activation exponent of a GroupNorm-ed split-tile input (cdx_gn_act_exp) from device / host gamma, beta."""
+    return _abi.gn_act_exp(gamma.detach().cpu().numpy(), beta.detach().cpu().numpy(), groups, hw)
+
+
+def gn_stats(src0, src1, gamma, beta, groups, eps=1e-5, want_moments=False, act_exp=None):
+    """(scale[B,C], shift[B,C]) such that group_norm(x)[b,...,c] = x*scale[b,c] + shift[b,c].
+    act_exp = "auto" | int: scale / shift are written times 2^exp and the result is (scale, shift, exp) -- pass it whole
+    as gn= to a convolution that takes the split tile (cdx.h gn_exp); the f32-MFMA tiles need the plain pair."""
     B = src0.shape[0]
     C = src0.shape[-1] + (0 if src1 is None else src1.shape[-1])
     dev = src0.device
@@ -235,9 +315,14 @@ def gn_stats(src0, src1, gamma, beta, groups, eps=1e-5, want_moments=False):
     shift = torch.empty(B, C, device=dev)
     mean = torch.empty(B, groups, device=dev) if want_moments else None
     rstd = torch.empty(B, groups, device=dev) if want_moments else None
-    a = gn_stats_args(src0, src1, gamma, beta, groups, scale, shift, eps, mean, rstd)
+    hw = src0.numel() // (B * src0.shape[-1])
+    e = 0 if act_exp is None else gn_act_exp(gamma, beta, groups, hw) if act_exp == "auto" else int(act_exp)
+    a = gn_stats_args(src0, src1, gamma, beta, groups, scale, shift, eps, mean, rstd, out_exp=e)
     wp, wb, keep = _ws(_abi.workspace_bytes("gn_stats_f32", a), dev)
     _call("gn_stats_f32", a, wp, wb, src0)
+    if act_exp is not None:
+        assert not want_moments
+        return scale, shift, e
     return (scale, shift, mean, rstd) if want_moments else (scale, shift)
 
 

@@ -12,6 +12,8 @@ the reference snapshot defines neither (README.md: 0 bytes), SURVEY.md Appendix 
 """
 from __future__ import annotations
 
+import ctypes
+
 import numpy as np
 import torch
 
@@ -33,6 +35,8 @@ class _Plan:
         cfg, g, dev = net.cfg, net.graph, net.device
         B, H, ch = batch, cfg["image_size"], cfg["base_channels"]
         self.calls = []          # (bound C function, args struct, ws_ptr, ws_bytes)
+        self.names = []          # layer name per recorded call (error messages, debug mode)
+        self.outs = {}           # conv layer name -> its output buffer (diagnostics)
         self._keep = []
         self._ws_need = 0
         self._ws_calls = []      # indices of calls that use the shared workspace
@@ -57,24 +61,28 @@ class _Plan:
         self._add("linear_f32", ops.linear_args(emb2, net.tproj_w, net.tproj_b, self.tproj, silu_in=True))
 
         stats_of = {}            # data_ptr of a conv output -> its fused partial-sum buffer
+        self.stats_of, self.gn_of = stats_of, {}      # (diagnostics: sums per tensor, (scale, shift, exp) per norm)
+        # Range bookkeeping of the split-fp16 tiles (cdx.h RANGE CONTRACT).  CDX_AMAX_WORDS int32 words per (tensor, image) in
+        # ONE arena, zeroed by the first launch of every forward: float32 bit patterns whose maximum is max |x| of that image,
+        # written by the producing convolution's epilogue (amax_out) or by a cdx_amax_f32 pass for tensors no convolution produced.
+        split = net.split and not half
+        self.amax_arena = self._hold(torch.zeros(4096 if split else 1, B, _abi.AMAX_WORDS, dtype=torch.int32, device=dev))
+        amax_slot = {}           # data_ptr of a tensor -> its row of the arena
+        need_amax = set()        # data_ptrs of conv outputs an un-normalised split launch reads
+        produced = {}            # data_ptr of a conv output -> the args struct of the launch that writes it
 
-        def gn(name, src0, src1=None):
-            """scale/shift of GroupNorm(cat[src0, src1]).  When every source was written by one of our convs the
-            sums come from that conv's epilogue (cdx_gn_finalize_f32: no extra pass over the activation)."""
-            c = src0.shape[-1] + (0 if src1 is None else src1.shape[-1])
-            sc, sh = new(B, c), new(B, c)
-            gamma, beta = net.dev[name + ".weight"], net.dev[name + ".bias"]
-            st0 = stats_of.get(src0.data_ptr())
-            st1 = None if src1 is None else stats_of.get(src1.data_ptr())
-            if (net.fuse_gn_stats or half) and st0 is not None and (src1 is None or st1 is not None):
-                hw = src0.shape[1] * src0.shape[2]
-                self._add("gn_finalize_f32", ops.gn_finalize_args(st0, st1, hw, gamma, beta, cfg["groups"], sc, sh))
-            else:
-                assert not half, "fp16 tensors always carry fused GroupNorm sums"
-                self._add("gn_stats_f32", ops.gn_stats_args(src0, src1, gamma, beta, cfg["groups"], sc, sh), ws=True)
-            return sc, sh
+        def amax_of(t):
+            k = t.data_ptr()
+            if k not in amax_slot:
+                amax_slot[k] = self.amax_arena[len(amax_slot)]
+            return amax_slot[k]
 
-        def conv(name, src0, src1=None, **kw):
+        if split:
+            self._add("fill_u32", _abi.FillU32Args(self.amax_arena.data_ptr(), self.amax_arena.numel(), 0), name="amax.zero")
+
+        def conv(name, src0, src1=None, norm=None, **kw):
+            """One convolution launch; norm = name of the GroupNorm fused on its input (its scale / shift launch is
+            recorded here, right before the convolution, with the activation exponent the chosen tile wants)."""
             pc = net.convs[name]
             Bn, hin, win, _ = src0.shape
             hv, wv = (2 * hin, 2 * win) if kw.get("upsample") else (hin, win)
@@ -83,49 +91,95 @@ class _Plan:
             normed_later = kw.pop("normed_later", False)     # a GroupNorm will read this output
             if out is None:
                 out = newa(Bn, (hv + s - 1) // s, (wv + s - 1) // s, pc.cout)
+            gnp = None
+            if norm is not None:
+                c = src0.shape[-1] + (0 if src1 is None else src1.shape[-1])
+                gnp = (new(B, c), new(B, c))
             if half:
-                a = ops.conv16_args(pc, src0, src1, out, **kw)
+                if norm is not None:
+                    gn_launch(norm, src0, src1, gnp, 0)
+                a = ops.conv16_args(pc, src0, src1, out, gn=gnp, **kw)
                 if normed_later:
                     stats_of[out.data_ptr()] = self._hold(ops.conv16_stats_buffer(a, dev))
-                self._add("conv_f16", a)
+                self._add("conv_f16", a, name=name)
                 return out
-            a = ops.conv_args(pc, src0, src1, out, **kw)
-            if normed_later and net.fuse_gn_stats:
+            a = ops.conv_args(pc, src0, src1, out, gn=gnp, **kw)
+            if split and norm is not None:
+                # GroupNorm-ed input: static exponent from the affine parameters, if the launch takes the split tile
+                hw = src0.shape[1] * src0.shape[2]
+                a.gn_exp = _abi.gn_act_exp(net.host[norm + ".weight"], net.host[norm + ".bias"], cfg["groups"], hw)
+                if _abi.lib().cdx_conv_select_tile(ctypes.byref(a)) != _abi.TILE_SPLIT:
+                    a.gn_exp = 0
+            elif split:
+                # un-normalised input: per-image maxima from the producers, if the launch takes the split tile with them
+                srcs = [src0] + ([src1] if src1 is not None else [])
+                a.src_amax0 = amax_of(src0).data_ptr()
+                a.src_amax1 = amax_of(src1).data_ptr() if src1 is not None else None
+                if _abi.lib().cdx_conv_select_tile(ctypes.byref(a)) == _abi.TILE_SPLIT:
+                    for t in srcs:
+                        if t.data_ptr() in produced:
+                            need_amax.add(t.data_ptr())
+                        elif t.data_ptr() != getattr(self.ctx, "data_ptr", lambda: 0)():
+                            # x_t | cond buffer, attention output: one pass over the tensor (ctx: once per decode, load_cond)
+                            self._add("amax_f32", _abi.AmaxArgs(t.data_ptr(), t.shape[-1], Bn, t.shape[1] * t.shape[2], t.shape[-1],
+                                                                amax_of(t).data_ptr()), name=name + ".amax_in")
+                else:
+                    a.src_amax0 = a.src_amax1 = None
+            if norm is not None:
+                gn_launch(norm, src0, src1, gnp, a.gn_exp)
+                self.gn_of[norm] = (gnp[0], gnp[1], a.gn_exp)
+            if normed_later and net.fuse_gn_stats:      # (asked AFTER the range fields are set: they decide the tile, the tile the slots)
                 stats_of[out.data_ptr()] = self._hold(ops.conv_stats_buffer(a, dev))
-            self._add("conv_f32", a)
+            produced[out.data_ptr()] = a
+            self.outs[name] = out
+            self._add("conv_f32", a, name=name)
             return out
+
+        def gn_launch(name, src0, src1, gnp, out_exp):
+            """scale/shift of GroupNorm(cat[src0, src1]) times 2^out_exp.  When every source was written by one of our
+            convs the sums come from that conv's epilogue (cdx_gn_finalize_f32: no extra pass over the activation)."""
+            sc, sh = gnp
+            gamma, beta = net.dev[name + ".weight"], net.dev[name + ".bias"]
+            st0 = stats_of.get(src0.data_ptr())
+            st1 = None if src1 is None else stats_of.get(src1.data_ptr())
+            if (net.fuse_gn_stats or half) and st0 is not None and (src1 is None or st1 is not None):
+                hw = src0.shape[1] * src0.shape[2]
+                self._add("gn_finalize_f32", ops.gn_finalize_args(st0, st1, hw, gamma, beta, cfg["groups"], sc, sh, out_exp=out_exp), name=name)
+            else:
+                assert not half, "fp16 tensors always carry fused GroupNorm sums"
+                self._add("gn_stats_f32", ops.gn_stats_args(src0, src1, gamma, beta, cfg["groups"], sc, sh, out_exp=out_exp), ws=True, name=name)
 
         def res(blk, x, skip=None):
             n = blk.name
-            h1 = conv(n + ".conv1", x, skip, gn=gn(n + ".norm1", x, skip), silu=True, normed_later=True,
+            h1 = conv(n + ".conv1", x, skip, norm=n + ".norm1", silu=True, normed_later=True,
                       temb=self.tproj, temb_off=net.tproj_off[n], temb_ld=self.tproj.shape[-1])
             if blk.cin != blk.cout:
                 r = conv(n + ".skip", x, skip)
             else:
                 assert skip is None
                 r = x
-            return conv(n + ".conv2", h1, gn=gn(n + ".norm2", h1), silu=True, residual=r, normed_later=True)
+            return conv(n + ".conv2", h1, norm=n + ".norm2", silu=True, residual=r, normed_later=True)
 
         def attn(blk, x):
             n = blk.name
             Bn, hh, ww, c = x.shape
-            qkv = conv(n + ".qkv", x, gn=gn(n + ".norm", x))
+            qkv = conv(n + ".qkv", x, norm=n + ".norm")
             o = newa(Bn, hh, ww, c)
             self._add(ops.ATTN_OP[adt], ops.attn_args(qkv, qkv, qkv, o, batch=Bn, nq=hh * ww, nk=hh * ww,
                                                  heads=c // cfg["head_dim"], head_dim=cfg["head_dim"],
-                                                 q_ld=3 * c, k_ld=3 * c, v_ld=3 * c, out_ld=c, k_off=c, v_off=2 * c))
+                                                 q_ld=3 * c, k_ld=3 * c, v_ld=3 * c, out_ld=c, k_off=c, v_off=2 * c), name=n + ".attn")
             return conv(n + ".proj", o, residual=x, normed_later=True)
 
         def xattn(blk, x):
             n = blk.name
             Bn, hh, ww, c = x.shape
-            q = conv(n + ".q", x, gn=gn(n + ".norm", x))
+            q = conv(n + ".q", x, norm=n + ".norm")
             kv = conv(n + ".kv", self.ctx)                       # [B, lh, lw, 2c]
             L = self.ctx.shape[1] * self.ctx.shape[2]
             o = newa(Bn, hh, ww, c)
             self._add(ops.ATTN_OP[adt], ops.attn_args(q, kv, kv, o, batch=Bn, nq=hh * ww, nk=L,
                                                  heads=c // cfg["head_dim"], head_dim=cfg["head_dim"],
-                                                 q_ld=c, k_ld=2 * c, v_ld=2 * c, out_ld=c, v_off=c))
+                                                 q_ld=c, k_ld=2 * c, v_ld=2 * c, out_ld=c, v_off=c), name=n + ".attn")
             return conv(n + ".proj", o, residual=x, normed_later=True)
 
         def run_block(blk, h, skip=None):
@@ -145,6 +199,9 @@ class _Plan:
             L, D = (H // 16) ** 2, cfg["context_dim"]
             lw = 32 if L % 32 == 0 else L
             self.ctx = self._hold(torch.zeros(B, L // lw, lw, D, device=dev, dtype=adt))
+            # the tokens do not change during a decode: their maxima live OUTSIDE the per-forward arena (load_cond fills them)
+            self.ctx_amax = self._hold(ops.amax_buffer(B, dev))
+            amax_slot[self.ctx.data_ptr()] = self.ctx_amax
 
         h = conv("conv_in", self.xin, normed_later=True)
         skips = [h]
@@ -157,7 +214,10 @@ class _Plan:
         for blk in g.up:
             h = run_block(blk, h, skips.pop() if blk.kind == "res" else None)
         assert not skips
-        conv("out.conv", h, gn=gn("out.norm", h), silu=True, out=self.eps, out_ld=self.eps.shape[-1])
+        conv("out.conv", h, norm="out.norm", silu=True, out=self.eps, out_ld=self.eps.shape[-1])
+        for k in need_amax:      # producers of the tensors an un-normalised split launch reads leave their maxima
+            produced[k].amax_out = amax_slot[k].data_ptr()
+        assert len(amax_slot) <= self.amax_arena.shape[0]
 
         # one shared workspace (calls are serialised on one stream)
         if self._ws_need:
@@ -171,12 +231,13 @@ class _Plan:
         self._keep.append(t)
         return t
 
-    def _add(self, op, args, ws=False):
+    def _add(self, op, args, ws=False, name=""):
         nbytes = _abi.workspace_bytes(op, args) if ws else 0
         if nbytes:
             self._ws_need = max(self._ws_need, nbytes)
             self._ws_calls.append(len(self.calls))
         self.calls.append((getattr(_abi.lib(), f"cdx_{op}"), args, None, nbytes))
+        self.names.append(name or op)
 
     def capture(self):
         """Record the launch list into a NEW hipGraph (torch.cuda.CUDAGraph on a side stream) and return it; the caller
@@ -192,19 +253,25 @@ class _Plan:
                 self.run()
         return g
 
-    def run(self, stream: int | None = None):
+    def run(self, stream: int | None = None, debug: bool = False):
         """Enqueue one UNet forward (eagerly) on `stream` (default: the current stream of the net's device): reads
         self.xin / self.t (/ self.ctx), writes self.eps.  hipLaunchKernelGGL launches on the CURRENT device, so the
-        net's device is made current for the duration."""
-        import ctypes
+        net's device is made current for the duration.  debug=True: after every float32 convolution its output is
+        checked by cdx_check_finite_f32 (one sync per layer) and the first layer that stores NaN / Inf raises."""
         dev = self.net.device
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
             byref = ctypes.byref
-            for fn, a, wp, wb in self.calls:
+            for i, (fn, a, wp, wb) in enumerate(self.calls):
                 rc = fn(byref(a), wp, wb, st)
                 if rc:
-                    _abi.check(rc, fn.__name__)
+                    _abi.check(rc, fn.__name__ + " [" + self.names[i] + "]")
+                if debug and fn.__name__ == "cdx_conv_f32":
+                    status = torch.zeros(1, dtype=torch.int32, device=dev)
+                    chk = _abi.CheckFiniteArgs(a.out, a.out_ld, a.batch * a.hout * a.wout, a.cout, 0.0, status.data_ptr())
+                    _abi.call("check_finite_f32", chk, None, 0, st)
+                    if int(status.item()):
+                        raise _abi.CdxError(f"UNet forward (debug): layer {self.names[i]} stored non-finite values")
 
 
 class UNet:
@@ -242,6 +309,7 @@ class UNet:
 
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)  # noqa: E731
         self.dev = {}      # small tensors used as-is: norms, linears
+        self.host = {}
         self.convs = {}    # name -> PackedConv
         res_blocks = [b for b in g.down + g.mid + g.up if b.kind == "res"]
         for name in g.param_shapes:
@@ -260,6 +328,8 @@ class UNet:
                                     ops.PackedConv(w, bias, c0, c1, self.device, split=split))
             elif ".norm" in name or name.startswith("temb."):
                 self.dev[name] = up(P[name])
+                if ".norm" in name:
+                    self.host[name] = P[name]        # host copies: the static activation exponents (cdx_gn_act_exp)
         for b in g.down + g.mid + g.up:
             if b.kind == "xattn":   # kv projection of the context tokens runs as a 1x1 convolution
                 w = P[b.name + ".kv.weight"]
@@ -307,3 +377,6 @@ def load_cond(p: _Plan, cfg: dict, cond: torch.Tensor) -> None:
         ops.cond_embed(c, p.xin, cfg["in_channels"])
     else:
         p.ctx.view(p.batch, -1, cfg["context_dim"]).copy_(cond.to(dev, torch.float32))   # (casts to fp16 when the plan is)
+        if p.ctx.dtype == torch.float32:
+            p.ctx_amax.zero_()
+            ops.amax(p.ctx, out=p.ctx_amax)

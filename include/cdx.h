@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 3
+#define CDX_ABI_VERSION 4
 
 typedef void* cdx_stream_t; /* hipStream_t */
 
@@ -58,6 +58,7 @@ enum {
 };
 
 #define CDX_CONV_KC 32 /* input-channel chunk of the packed weight layout */
+#define CDX_AMAX_WORDS 16 /* words per image of the amax arrays (src_amax0/1, amax_out, cdx_amax_f32) */
 
 typedef struct cdx_conv_args {
     const float* src0;     /* [batch, hin, win, c0] */
@@ -83,13 +84,36 @@ typedef struct cdx_conv_args {
                               result up to summation order, 2.25x fewer MFMAs */
     double* stats_out;     /* NULL, or [batch, cdx_conv_stats_slots(a), cout, 2]: per-slot (sum, sum of squares) of the
                               values stored to `out`, float64, for cdx_gn_finalize_f32 (GroupNorm of `out` without
-                              re-reading it) */
+                              re-reading it).  Every (slot, channel) entry is written by the launch (unused ones as 0):
+                              the buffer needs no initialisation. */
     const uint16_t* wpacked_split; /* NULL, or the cdx_conv_pack_weights_split_f16 image of the same weights (fp16 hi | lo
-                              planes, pre-scaled by a power of two): lets the library run stride-1 layers with
-                              wout >= 32 on the FP16 matrix pipe with split operands (hi*hi + lo*hi + hi*lo, float32
-                              accumulation) -- float32-level error, 3 MFMAs of 32 cycles per 16 channels where the
-                              f32-input MFMA needs 8 of 64 */
+                              planes, pre-scaled by a power of two): lets the library run layers >= 8 pixels wide
+                              (stride 2: >= 16) on the FP16 matrix pipe with split operands (hi*hi + lo*hi + hi*lo,
+                              float32 accumulation), 3 MFMAs of 32 cycles per 16 channels where the f32-input MFMA needs
+                              8 of 64.  RANGE CONTRACT (ABI v4): the activations are staged as x 2^e with a power of two
+                              e that places the tensor's maximum in [2^14, 2^15), so the result keeps float32-level
+                              error relative to the OUTPUT scale at ANY input scale.  e comes from
+                                * gn_exp       for CDX_CONV_GN launches (static: the normalised tensor's bound), or
+                                * src_amax0/1  for un-normalised launches (per image, from the producing launches);
+                              an un-normalised launch WITHOUT src_amax0 (or without src_amax1 when c1 > 0) never takes
+                              the split tile: it runs on the f32-input MFMA kernels, which need no scaling.
+                              NaN / +-Inf inputs propagate as in F.conv2d (non-finite outputs over their footprint). */
     float wsplit_unscale;  /* the packer's `unscale` output (2^-s, exact); > 0 whenever wpacked_split is set */
+    int32_t gn_exp;        /* CDX_CONV_GN: gn_scale / gn_shift hold scale 2^gn_exp, shift 2^gn_exp (cdx_gn_*_args.out_exp of
+                              the launch that wrote them; |gn_exp| <= 60); the kernels undo it exactly.  0 = plain. */
+    const uint32_t* src_amax0; /* NULL, or device [batch][CDX_AMAX_WORDS]: float32 BIT PATTERNS whose maximum is an upper bound
+                              of max |x| over image b of src0 -- the `amax_out` words of the launch that produced src0, or
+                              cdx_amax_f32's output (64-byte aligned) */
+    const uint32_t* src_amax1; /* the same for src1 (c1 > 0) */
+    int32_t stats_slots;   /* with stats_out: the slot count the buffer was sized for = cdx_conv_stats_slots(a) asked with EVERY
+                              other field final (the range fields above decide the tile, the tile the slots); a launch
+                              whose tile writes a different count returns CDX_EINVAL instead of overrunning the buffer */
+    uint32_t* amax_out;    /* NULL, or device [batch][CDX_AMAX_WORDS]: every wave max-combines (atomic, unsigned compare = float
+                              compare for non-negative values) the bit pattern of the largest |out[b]| it stores into ONE of
+                              image b's words (NaNs skipped; +-Inf counts): max over the words = max |out[b]|.  Several words
+                              per image because same-address atomics serialise in L2 (measured: +14 us on a 150 us launch
+                              with one word).  The CALLER zeroes them before the first launch that writes them
+                              (cdx_fill_u32).  Honoured by every tile shape. */
 } cdx_conv_args;
 
 int cdx_conv_f32(const cdx_conv_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
@@ -113,7 +137,9 @@ enum {
     CDX_TILE_SMALL = 8,   /* 3x3 stride 1, cout <= 4, width >= 32: 4x4x1-MFMA kernel, 256 pixels  */
     CDX_TILE_SMALL_VALU = 9, /* the same tile on the vector ALU (weights through the scalar cache)  */
     CDX_TILE_CIN8 = 10,   /* 3x3 stride 1, at most 8 input channels (conv_in): 128x128, first channel group only */
-    CDX_TILE_SPLIT = 11   /* stride 1, wout >= 32: 128x128 on v_mfma_f32_32x32x16_f16 with hi/lo split operands, needs wpacked_split */
+    CDX_TILE_SPLIT = 11   /* v_mfma_f32_32x32x16_f16 with hi/lo split operands (needs wpacked_split and an activation exponent, see
+                             cdx_conv_args): 128 px x 128 ch at wout >= 32, 64 x 128 at wout 16..31 and for stride 2 (wout >= 16),
+                             64 px x 32 ch with the input chunks split over the waves at wout 8..15 */
 };
 int cdx_conv_select_tile(const cdx_conv_args* a);
 int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
@@ -197,6 +223,9 @@ typedef struct cdx_gn_stats_args {
     float* shift;       /* [batch, c0+c1] */
     float* mean;        /* [batch, groups] or NULL (diagnostic) */
     float* rstd;        /* [batch, groups] or NULL */
+    int32_t out_exp;    /* scale and shift are written multiplied by 2^out_exp (exact; |out_exp| <= 60): pass the same
+                           value as cdx_conv_args.gn_exp of the convolution that consumes them.  cdx_gn_act_exp() gives
+                           the value that keeps the normalised tensor inside the fp16 range of the split tile. */
 } cdx_gn_stats_args;
 
 int cdx_gn_stats_f32(const cdx_gn_stats_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
@@ -216,10 +245,18 @@ typedef struct cdx_gn_finalize_args {
     float* shift;
     float* mean;        /* [batch, groups] or NULL */
     float* rstd;
+    int32_t out_exp;    /* as cdx_gn_stats_args.out_exp */
 } cdx_gn_finalize_args;
 
 int cdx_gn_finalize_f32(const cdx_gn_finalize_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
 size_t cdx_gn_finalize_f32_workspace(const cdx_gn_finalize_args* a);
+
+/* HOST: the activation exponent of a GroupNorm-ed convolution input (gn_exp / out_exp above).  After GroupNorm every value
+ * obeys |x^| <= sqrt(n - 1), n = elements per (image, group) = (channels / groups) * hw, so
+ * |gamma_c x^ + beta_c| <= bound = max_c |gamma_c| sqrt(n) + max_c |beta_c| (SiLU only shrinks magnitudes).  Returns the
+ * largest e with bound * 2^e < 2^15, clamped to [-60, 60] (0 for a zero or non-finite bound): staged values can then never
+ * leave the fp16 range, and a unit-variance tensor sits 2^e above the range where the split's low part loses bits. */
+int32_t cdx_gn_act_exp(const float* gamma_host, const float* beta_host, int32_t channels, int32_t groups, int32_t hw);
 
 /* ------------------------------------------------------------------------------------------
  * U6/U7: multi-head attention core  out = softmax(q k^T * scale) v  on fp32 MFMA.
@@ -338,6 +375,44 @@ typedef struct cdx_tile_blend_args {
 
 int cdx_tile_blend_f32(const cdx_tile_blend_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
 size_t cdx_tile_blend_f32_workspace(const cdx_tile_blend_args* a);
+
+/* ------------------------------------------------------------------------------------------
+ * Range bookkeeping of the split tile (cdx_conv_args.src_amax0/1, amax_out) and debug checks.
+ * ------------------------------------------------------------------------------------------ */
+/* max_k out[b][k] = max(itself, bit pattern of max_{p < n, c < channels} |x[b][p][c]|)  (NaNs skipped; atomic max-combine
+ * spread over the CDX_AMAX_WORDS words of image b: zero `out` first with cdx_fill_u32 unless the combination with earlier
+ * producers is wanted).  For tensors no convolution
+ * of this library produced: caller data (latent, context tokens), the sampler's x_t | cond buffer, attention outputs. */
+typedef struct cdx_amax_args {
+    const float* x; int32_t x_ld; /* [batch, n, x_ld] */
+    int32_t batch, n, channels;   /* channels <= x_ld, multiples of 4 */
+    uint32_t* out;                /* device [batch][CDX_AMAX_WORDS], 64-byte aligned */
+} cdx_amax_args;
+
+int cdx_amax_f32(const cdx_amax_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_amax_f32_workspace(const cdx_amax_args* a);
+
+/* x[0 .. n) = value (32-bit words): zeroes the amax words / status words at the start of a forward pass. */
+typedef struct cdx_fill_u32_args {
+    uint32_t* x; int64_t n; uint32_t value;
+} cdx_fill_u32_args;
+
+int cdx_fill_u32(const cdx_fill_u32_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_fill_u32_workspace(const cdx_fill_u32_args* a);
+
+/* Debug: *status |= 1 if any of x[b][p][c], c < channels, is NaN or +-Inf; |= 2 if any |x| exceeds `limit` (limit > 0).
+ * The Python host runs it after every launch in debug mode (ops.conv(..., debug=True), Plan.run(debug=True)) and raises
+ * on a non-zero word; the product path never launches it. */
+typedef struct cdx_check_finite_args {
+    const float* x; int32_t x_ld;
+    int64_t rows;                 /* batch * pixels */
+    int32_t channels;
+    float limit;                  /* 0 = no magnitude check */
+    int32_t* status;              /* device int32, caller-zeroed */
+} cdx_check_finite_args;
+
+int cdx_check_finite_f32(const cdx_check_finite_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_check_finite_f32_workspace(const cdx_check_finite_args* a);
 
 /* ------------------------------------------------------------------------------------------
  * (f4) Bitstream side: rANS decode of the quantised latent (format build-defined, "CDXL" v1).

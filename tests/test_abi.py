@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(cdx._abi.EXPORTS), declared ^ set(cdx._abi.EXPORTS)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.cdx_abi_version() == 3
+    assert lib.cdx_abi_version() == 4
     assert b"workspace" in lib.cdx_strerror(-2) and lib.cdx_strerror(0) == b"ok"
 
 
@@ -32,7 +32,9 @@ def test_struct_layouts_match_c(tmp_path):
     structs = {"cdx_conv_args": A.ConvArgs, "cdx_conv_f16_args": A.ConvF16Args, "cdx_gn_stats_args": A.GnStatsArgs, "cdx_gn_finalize_args": A.GnFinalizeArgs, "cdx_attn_args": A.AttnArgs,
                "cdx_linear_args": A.LinearArgs, "cdx_timestep_embedding_args": A.TimestepEmbeddingArgs,
                "cdx_diffusion_update_args": A.DiffusionUpdateArgs, "cdx_gauss_fill_args": A.GaussFillArgs,
-               "cdx_cond_embed_args": A.CondEmbedArgs, "cdx_export_image_args": A.ExportImageArgs, "cdx_tile_blend_args": A.TileBlendArgs}
+               "cdx_cond_embed_args": A.CondEmbedArgs, "cdx_export_image_args": A.ExportImageArgs, "cdx_tile_blend_args": A.TileBlendArgs,
+               "cdx_rans_decode_args": A.RansDecodeArgs, "cdx_amax_args": A.AmaxArgs, "cdx_fill_u32_args": A.FillU32Args,
+               "cdx_check_finite_args": A.CheckFiniteArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -22,12 +22,16 @@ def _run(cmd):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("launcher", ["plain", "torchrun"])
+@pytest.mark.parametrize("launcher", ["plain", "torchrun", "self_launch"])
 def test_bench_line_contract(lib, launcher):
     args = ["bench.py", "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-sample-call"]
-    cmd = [sys.executable] + args if launcher == "plain" else \
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-         "--master-port", "29571"] + args
+    if launcher == "plain":
+        cmd = [sys.executable] + args
+    elif launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", "29571"] + args
+    else:      # the path `python bench.py --gpus N` takes for N > 1 when no launcher is around it (bench.launch_ranks), at N = 1
+        cmd = [sys.executable, "-c", "import sys, bench; sys.exit(bench.launch_ranks(1, %r))" % args[1:]]
     d = _run(cmd)
     assert KEYS <= set(d), KEYS - set(d)
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["unit"] == "images/s" and d["scaling"] == "weak"
@@ -38,3 +42,12 @@ def test_bench_line_contract(lib, launcher):
     roof = d["roofline"]
     assert roof["bound"] in ("mfma", "hbm") and 0 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert roof["traffic"] is None or roof["traffic"] > 0
+    # SURVEY 8(d) / VERDICT r02 item 3: frac is ALGORITHMIC work over the peak of the pipe used; the float32 path issues 3 fp16
+    # MFMAs per product, so it cannot exceed 1/3 of that peak, and the pipe utilisation is named separately
+    assert roof["frac_algorithmic"] == roof["frac"] and roof["emulation_factor"] == 3
+    assert roof["frac_algorithmic"] <= 1.0 / roof["emulation_factor"]
+    assert abs(roof["mfma_pipe_utilisation"] - roof["emulation_factor"] * roof["frac_algorithmic"]) < 2e-3 and roof["mfma_pipe_utilisation"] <= 1.0
+    if launcher == "plain":      # the conservative float32 number is timed in the same (driver-run) command
+        sf = d["strict_f32"]
+        assert sf["images_per_s"] > 0 and sf["images_per_s"] < d["value"] and abs(sf["images_per_s"] - 16 / (100 * sf["ms_per_step"] * 1e-3)) <= 2e-3 * sf["images_per_s"]
+        assert abs(sf["frac_of_f32_mfma_peak"] - sf["algorithmic_tflops_whole_step"] / sf["peak"]) < 1e-3

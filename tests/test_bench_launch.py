@@ -1,0 +1,44 @@
+"""`python bench.py --gpus N` must work unassisted (VERDICT r02 "missing" 3): with N > 1 and no launcher around it, bench.py starts
+the ranks itself as a child process.  Checked here without a GPU: (a) the same launch function with a CPU stand-in sampler
+(tests/bench_entry_oracle.py, gloo) prints exactly ONE JSON line with n_gpus 2 and the contract keys; (b) the plain command
+propagates a failing child's status (no GPU here: every rank refuses to run) instead of printing a line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config"}
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_through_the_self_launch_path_print_one_line():
+    argv = ["--gpus", "2", "--config", "cfg1", "--steps", "2", "--warmup", "1", "--no-sample-call", "--no-cpu-baseline"]
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.launch_ranks(2, %r, entry=%r))" % (ROOT, argv, os.path.join(ROOT, "tests", "bench_entry_oracle.py")))
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert KEYS <= set(d)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["global_batch"] == 2 and d["scaling"] == "weak"
+    assert d["value"] > 0 and "injected" in d["backend"] and "roofline" not in d and "cpu_baseline" not in d
+    # whole-job rate: images of BOTH ranks per second
+    assert abs(d["value"] - 2 / (50 * d["ms_per_step"] * 1e-3)) <= 2e-3 * d["value"]
+
+
+@pytest.mark.timeout(300)
+def test_plain_multi_gpu_command_launches_children_and_propagates_failure():
+    """No GPU in this container: the children exit with an error, and so must the parent -- without a JSON line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the children would run the real bench")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "needs a GPU" in r.stdout + r.stderr

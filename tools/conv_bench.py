@@ -20,6 +20,7 @@ ap.add_argument("--gn", action="store_true", help="fuse GroupNorm scale/shift + 
 ap.add_argument("--stamps", type=int, default=0, help="tile id of a stamping variant (92): run it once and digest the per-wave phase stamps")
 ap.add_argument("--check", action="store_true", help="compare every tile's output with the first tile's")
 ap.add_argument("--stats", action="store_true", help="also produce the GroupNorm partial sums of the output (as every normed layer of the UNet does)")
+ap.add_argument("--no-amax", action="store_true", help="with --stats: do not request amax_out")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 a = ap.parse_args()
@@ -32,11 +33,19 @@ pc = ops.PackedConv(w, np.zeros(co, np.float32), c0, c1)
 ho, wo = (H, W) if s == 1 else ((H + 1) // 2, (W + 1) // 2)
 out = torch.empty(B, ho, wo, co, device="cuda")
 kw = {}
+_tiles = [int(t) for t in a.tiles.split(",")]
 if a.gn:
     gamma, beta = torch.ones(c0 + c1, device="cuda"), torch.zeros(c0 + c1, device="cuda")
-    kw = dict(gn=ops.gn_stats(x0, x1, gamma, beta, 32), silu=True, temb=torch.randn(B, co, device="cuda"),
+    # split tiles only: GroupNorm scale / shift pre-multiplied by the static activation exponent, as the UNet plan does
+    exp = "auto" if all(t == 11 or t >= 60 for t in _tiles) else None
+    kw = dict(gn=ops.gn_stats(x0, x1, gamma, beta, 32, act_exp=exp), silu=True, temb=torch.randn(B, co, device="cuda"),
               residual=torch.randn(B, ho, wo, co, device="cuda"))
+else:      # un-normalised launch: the split tile takes its exponent from the per-image maxima of the sources
+    kw = dict(src_amax=(ops.amax(x0),) + ((ops.amax(x1),) if x1 is not None else ()))
 args = ops.conv_args(pc, x0, x1, out, stride=s, **kw)
+if a.stats and not a.no_amax:      # ... and leaves the maxima of its output, as every block output of the UNet does
+    _amax_keep = ops.amax_buffer(B, "cuda")
+    args.amax_out = _amax_keep.data_ptr()
 if a.stats:
     _stats_keep = ops.conv_stats_buffer(args, "cuda")
     _stats_big = torch.zeros(4 * _stats_keep.numel(), dtype=torch.float64, device="cuda")      # variants with more slots per tile
