@@ -109,6 +109,19 @@ class CheckFiniteArgs(C.Structure):
     _fields_ = [("x", _f), ("x_ld", _i), ("rows", C.c_int64), ("channels", _i), ("limit", C.c_float), ("status", _f)]
 
 
+class ExportU8Args(C.Structure):
+    _fields_ = [("x", _f), ("x_ld", _i), ("batch", _i), ("hw", _i), ("channels", _i), ("lo", C.c_float), ("hi", C.c_float), ("out", _f)]
+
+
+class PsnrArgs(C.Structure):
+    _fields_ = [("a", _f), ("b", _f), ("batch", _i), ("n", C.c_int64), ("range", C.c_float), ("out", _f)]
+
+
+class MsssimArgs(C.Structure):
+    _fields_ = [("x", _f), ("y", _f), ("batch", _i), ("channels", _i), ("h", _i), ("w", _i), ("range", C.c_float),
+                ("out", _f), ("per_scale", _f)]
+
+
 class TileBlendArgs(C.Structure):
     _fields_ = [("tiles", _f), ("batch", _i), ("channels", _i), ("tile", _i), ("ny", _i), ("nx", _i),
                 ("y0", _f), ("x0", _f), ("h", _i), ("w", _i), ("out", _f)]
@@ -134,6 +147,9 @@ OPS = {
     "amax_f32": AmaxArgs,
     "fill_u32": FillU32Args,
     "check_finite_f32": CheckFiniteArgs,
+    "export_u8": ExportU8Args,
+    "psnr_f32": PsnrArgs,
+    "msssim_f32": MsssimArgs,
 }
 
 # every exported symbol include/cdx.h declares (checked by tests/test_abi.py without a GPU)

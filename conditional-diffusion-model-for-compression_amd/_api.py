@@ -23,3 +23,7 @@ from . import bitstream
 from .bitstream import LatentDecoder, parse_latent_stream, decode_bitstreams
 
 __all__ += ["bitstream", "LatentDecoder", "parse_latent_stream", "decode_bitstreams"]
+from . import image_io
+from .image_io import to_uint8, write_image, write_images, encode_png, encode_ppm, psnr, ms_ssim
+
+__all__ += ["image_io", "to_uint8", "write_image", "write_images", "encode_png", "encode_ppm", "psnr", "ms_ssim"]

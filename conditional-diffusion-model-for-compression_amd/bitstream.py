@@ -30,6 +30,9 @@ from . import _abi
 MAGIC, VERSION = b"CDXL", 1
 
 
+MAX_LATENT_SIDE, MAX_LATENT_CHANNELS = 1024, 1024      # reader limits (16384^2 images)
+
+
 def parse_latent_stream(buf: bytes) -> dict:
     """Validate and split one CDXL container (host, numpy views; raises ValueError on any inconsistency)."""
     buf = bytes(buf)
@@ -42,6 +45,11 @@ def parse_latent_stream(buf: bytes) -> dict:
     alphabet = 2 * qmax + 1
     if not (1 <= pb <= 12) or alphabet > (1 << pb) or cz == 0 or h == 0 or w == 0 or not np.isfinite(step):
         raise ValueError("CDXL header out of range")
+    # an untrusted 40-byte container must not be able to request gigabytes or a minutes-long serial decode:
+    # latents are images / 16 (8192^2 images: 512 x 512), and a symbol costs at least ~1/16 bit of payload per the
+    # table's most probable symbol (freq <= 2^pb - alphabet + 1), so nsym is bounded by the payload it is decoded from
+    if h > MAX_LATENT_SIDE or w > MAX_LATENT_SIDE or cz > MAX_LATENT_CHANNELS:
+        raise ValueError(f"CDXL latent {cz} x {h} x {w} exceeds the reader's limits ({MAX_LATENT_CHANNELS} x {MAX_LATENT_SIDE}^2)")
     pos = 24
     nfreq = alphabet + (alphabet & 1)
     need = pos + 2 * nfreq + 8 * cz + 2 * nwords
@@ -58,6 +66,13 @@ def parse_latent_stream(buf: bytes) -> dict:
         raise ValueError("CDXL frequency table does not sum to 2^prob_bits or has an empty symbol")
     if ((off.astype(np.int64) + ln) > nwords).any() or (ln < 2).any():
         raise ValueError("CDXL stream table points outside the payload")
+    # each renormalisation word carries 16 bits; a symbol of probability p costs -log2 p bits: h*w symbols of the MOST probable
+    # symbol need at least h*w * -log2(fmax / 2^pb) bits (minus the 32-bit final state)
+    fmax = int(freq.max())
+    if fmax < (1 << pb):
+        min_bits = h * w * -np.log2(fmax / float(1 << pb))
+        if (16.0 * ln.astype(np.float64) + 32.0 < min_bits - 64.0).any():
+            raise ValueError("CDXL stream is too short for the symbol count its header claims")
     return dict(prob_bits=pb, channels=cz, height=h, width=w, qmax=qmax, step=float(step), freq=freq, off=off, len=ln, words=words)
 
 
@@ -75,6 +90,8 @@ class LatentDecoder:
     @torch.no_grad()
     def decode(self, containers, return_symbols: bool = False):
         parsed = [parse_latent_stream(b) for b in containers]
+        if not parsed:
+            raise ValueError("LatentDecoder.decode: no containers")
         p0 = parsed[0]
         for p in parsed[1:]:
             same = all(p[k] == p0[k] for k in ("prob_bits", "channels", "height", "width", "qmax", "step")) and \
@@ -110,7 +127,17 @@ class LatentDecoder:
 
 
 @torch.no_grad()
-def decode_bitstreams(sampler, ctx, containers, steps: int, **kw) -> torch.Tensor:
-    """bytes -> latent -> conditioning -> reverse diffusion: the whole decode path of the codec's synthesis side."""
+def decode_bitstreams(sampler, ctx, containers, steps: int, *, out_path: str | None = None, **kw) -> torch.Tensor:
+    """bytes -> latent -> conditioning -> reverse diffusion: the whole decode path of the codec's synthesis side.
+    out_path ("x.png" / "x.ppm"): also write the decoded images as 8-bit files (one: the path as given; several:
+    x_0000.png, ...), quantised on the device straight from the sampler's state buffer (cdx_export_u8)."""
     z = LatentDecoder(sampler.unet.device)(containers)
-    return sampler.sample(ctx(z), steps, **kw)
+    cond = ctx(z)
+    if out_path is None:
+        return sampler.sample(cond, steps, **kw)
+    from .image_io import to_uint8, write_images
+    run = sampler.begin(cond, steps, **kw)
+    for k in range(steps):
+        sampler.step(run, k)
+    write_images(out_path, to_uint8(run.plan.xin, nhwc_channels=run.channels))
+    return sampler.finish(run)

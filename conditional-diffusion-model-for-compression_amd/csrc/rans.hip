@@ -11,7 +11,8 @@
 // the mapping is simply lane = stream: 64 streams per wave walk their symbols in lockstep, the slot -> symbol table and
 // the cumulative frequencies sit in LDS (built once per workgroup), words are gathered per lane, and the dequantised
 // values are written symbol-major.  Malformed input never reads out of bounds: a stream that runs past its length or
-// does not end in the encoder's initial state sets *status instead.
+// does not end in the encoder's initial state sets *status instead and STOPS (its remaining outputs are zero-filled); a
+// frequency table that does not sum to 2^prob_bits (slots without a symbol) sets *status and decodes nothing.
 #include "common.h"
 
 using namespace cdx;
@@ -30,15 +31,19 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint16_t* __rest
     __shared__ uint16_t slot2sym[1 << kMaxProbBits];
     const int tid = threadIdx.x;
     const uint32_t M = 1u << prob_bits;
+    __shared__ uint32_t total;
     if (tid == 0) {                                      // alphabet is small (2 qmax + 1): a serial prefix sum
         uint32_t c = 0;
         for (int s = 0; s < alphabet; ++s) {
-            cum[s] = (uint16_t)c;
+            cum[s] = (uint16_t)(c < 0xFFFFu ? c : 0xFFFFu);      // (a table that overshoots fails the total == M check)
             fr[s] = freq[s];
             c += freq[s];
         }
+        total = c;
     }
+    for (uint32_t k = tid; k < M; k += blockDim.x) slot2sym[k] = 0;          // no slot is ever left uninitialised
     __syncthreads();
+    const bool table_ok = total == M;                    // the device trusts no table: slots without a symbol would index past fr / cum
     for (int s = tid; s < alphabet; s += blockDim.x)
         for (uint32_t k = cum[s], e = min((uint32_t)cum[s] + fr[s], M); k < e; ++k) slot2sym[k] = (uint16_t)s;
     __syncthreads();
@@ -47,20 +52,25 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint16_t* __rest
     if (st >= nstreams) return;
     const uint16_t* w = words + off[st];
     const uint32_t n = len[st];
-    bool bad = n < 2;
+    bool bad = n < 2 || !table_ok;
     uint32_t x = bad ? kRansL : ((uint32_t)w[0] << 16) | w[1];
     uint32_t pos = 2;
-    for (int i = 0; i < nsym; ++i) {
+    int i = 0;
+    for (; i < nsym && !bad; ++i) {
         const uint32_t slot = x & (M - 1);
         const uint32_t s = slot2sym[slot];
         x = (uint32_t)fr[s] * (x >> prob_bits) + slot - cum[s];
         if (x < kRansL) {
             if (pos < n) x = (x << 16) | w[pos++];
-            else bad = true;
+            else bad = true;                             // ran past the stream: stop (the loop must not spin on garbage)
         }
         const int q = (int)s - qmax;
         out[(size_t)st * nsym + i] = (float)q * step;
         if (symbols) symbols[(size_t)st * nsym + i] = (int16_t)q;
+    }
+    for (; i < nsym; ++i) {                              // a stream that stopped early: defined (zero) outputs
+        out[(size_t)st * nsym + i] = 0.f;
+        if (symbols) symbols[(size_t)st * nsym + i] = 0;
     }
     if (x != kRansL || pos != n) bad = true;             // the encoder starts from state 2^16 and every word must be consumed
     if (bad && status) atomicOr(status, 1);

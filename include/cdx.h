@@ -289,7 +289,7 @@ typedef struct cdx_linear_args {
     const float* x; int32_t x_ld; /* [m, x_ld] */
     const float* w;               /* [n, k] row-major (torch layout) */
     const float* bias;            /* [n] or NULL */
-    int32_t m, n, k;              /* k multiple of 4, k <= 1024 (else CDX_ENOTSUP); any m */
+    int32_t m, n, k;              /* k multiple of 4; any m, any k */
     int32_t flags;
     float* out; int32_t out_ld;
 } cdx_linear_args;
@@ -440,6 +440,48 @@ typedef struct cdx_rans_decode_args {
 
 int cdx_rans_decode_i16(const cdx_rans_decode_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
 size_t cdx_rans_decode_i16_workspace(const cdx_rans_decode_args* a);
+
+/* ------------------------------------------------------------------------------------------
+ * (f4) Image side: 8-bit export of the decoded tensor and the two quality metrics of the codec literature.
+ * ------------------------------------------------------------------------------------------ */
+/* out[b][p][c] = floor((clamp(x[b][p][c], lo, hi) - lo) * 255 / (hi - lo) + 0.5) as uint8, c < channels: interleaved rows, the
+ * scanline order of PPM (P6) and PNG; x is the NHWC state buffer of the sampler (x_ld floats per pixel). */
+typedef struct cdx_export_u8_args {
+    const float* x; int32_t x_ld;
+    int32_t batch, hw, channels;
+    float lo, hi;
+    uint8_t* out;                 /* device [batch, hw, channels] */
+} cdx_export_u8_args;
+
+int cdx_export_u8(const cdx_export_u8_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_export_u8_workspace(const cdx_export_u8_args* a);
+
+/* out[i] = 10 log10(range^2 / mean((a[i] - b[i])^2)) over the n elements of image i (float64 sums, fixed order; +inf if equal). */
+typedef struct cdx_psnr_args {
+    const float* a; const float* b; /* [batch, n] */
+    int32_t batch; int64_t n;
+    float range;                  /* peak-to-peak of the data (2 for [-1, 1]) */
+    float* out;                   /* device [batch] */
+} cdx_psnr_args;
+
+int cdx_psnr_f32(const cdx_psnr_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_psnr_f32_workspace(const cdx_psnr_args* a);
+
+/* Multi-scale SSIM (Wang, Simoncelli, Bovik 2003) per image of NCHW tensors: 5 scales, 11 x 11 Gaussian window (sigma 1.5, valid
+ * support), 2 x 2 average pooling between scales, C1 = (0.01 range)^2, C2 = (0.03 range)^2,
+ *   out[b] = prod_{j<4} mean(cs_j)^w_j * mean(ssim_4)^w_4,  w = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333),
+ * means over the channels and valid pixels of image b (negative means clamp to 0).  h, w >= 176.  per_scale (optional)
+ * receives the five means. */
+typedef struct cdx_msssim_args {
+    const float* x; const float* y; /* [batch, channels, h, w] */
+    int32_t batch, channels, h, w;
+    float range;
+    float* out;                   /* device [batch] */
+    float* per_scale;             /* device [batch, 5] or NULL */
+} cdx_msssim_args;
+
+int cdx_msssim_f32(const cdx_msssim_args* a, void* workspace, size_t workspace_bytes, cdx_stream_t stream);
+size_t cdx_msssim_f32_workspace(const cdx_msssim_args* a);
 
 /* Diagnostics: monotonically counts kernel launches made through this library (relaxed atomic;
  * the only process-global the library keeps, used by tests to prove the HIP path ran). */

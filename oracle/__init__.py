@@ -20,7 +20,9 @@ from .context_ref import context_forward_ref
 from .bitstream_ref import (quantise_ref, build_freq_ref, rans_encode_ref, rans_decode_ref, encode_latent_ref,
                             decode_latent_ref)
 
-__all__ = ["unet_forward_ref", "timestep_embedding_ref", "sample_ref", "make_schedule_ref",
+from .metrics_ref import to_uint8_ref, psnr_ref, msssim_ref, read_ppm_ref, read_png_ref
+
+__all__ = ["to_uint8_ref", "psnr_ref", "msssim_ref", "read_ppm_ref", "read_png_ref", "unet_forward_ref", "timestep_embedding_ref", "sample_ref", "make_schedule_ref",
            "step_coefficients_ref", "normal_ref", "uniform_ref", "stream_key_ref",
            "sample_tiled_ref", "blend_ref", "origins_ref", "context_forward_ref", "quantise_ref", "build_freq_ref", "rans_encode_ref", "rans_decode_ref",
            "encode_latent_ref", "decode_latent_ref"]

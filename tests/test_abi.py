@@ -34,7 +34,8 @@ def test_struct_layouts_match_c(tmp_path):
                "cdx_diffusion_update_args": A.DiffusionUpdateArgs, "cdx_gauss_fill_args": A.GaussFillArgs,
                "cdx_cond_embed_args": A.CondEmbedArgs, "cdx_export_image_args": A.ExportImageArgs, "cdx_tile_blend_args": A.TileBlendArgs,
                "cdx_rans_decode_args": A.RansDecodeArgs, "cdx_amax_args": A.AmaxArgs, "cdx_fill_u32_args": A.FillU32Args,
-               "cdx_check_finite_args": A.CheckFiniteArgs}
+               "cdx_check_finite_args": A.CheckFiniteArgs, "cdx_export_u8_args": A.ExportU8Args, "cdx_psnr_args": A.PsnrArgs,
+               "cdx_msssim_args": A.MsssimArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

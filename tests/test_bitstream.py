@@ -55,3 +55,19 @@ def test_parser_rejects_malformed_containers():
     with pytest.raises(ValueError, match="outside"):
         cdx.parse_latent_stream(bytes(broken))
     assert p["words"].size == struct.unpack_from("<I", good, 20)[0]
+
+
+def test_parser_bounds_what_a_tiny_container_can_request():
+    """a ~40-byte hostile container must not be able to ask for 2^31 symbols per stream."""
+    good = np.load(GOLD)["container"].tobytes()
+    huge = bytearray(good)
+    struct.pack_into("<2H", huge, 10, 65535, 65535)          # h, w (header: magic, version, pb, cz, h, w, qmax)
+    with pytest.raises(ValueError, match="limits"):
+        cdx.parse_latent_stream(bytes(huge))
+    # within the side limits, but far more symbols than the payload's bits can encode
+    p = cdx.parse_latent_stream(good)
+    many = bytearray(good)
+    struct.pack_into("<2H", many, 10, 1024, 1024)
+    with pytest.raises(ValueError, match="too short"):
+        cdx.parse_latent_stream(bytes(many))
+    assert p["height"] * p["width"] < 1024 * 1024

@@ -66,6 +66,44 @@ def test_corrupt_payload_is_reported_not_crashed(cdx_mod):
         cdx_mod.LatentDecoder()([bytes(g), other])
 
 
+def test_device_refuses_a_bad_frequency_table_and_stops_on_a_short_stream(cdx_mod):
+    """the kernel trusts no table (sum != 2^prob_bits -> status, nothing decoded: no slot without a symbol is ever
+    looked up) and a stream that runs dry stops instead of spinning through its remaining symbols."""
+    A = cdx_mod._abi
+    rng = np.random.default_rng(5)
+    q = oracle.quantise_ref(rng.standard_normal((2, 16, 16)) * 3.0, 0.5, 15)
+    g = cdx_mod.parse_latent_stream(oracle.encode_latent_ref(q, 0.5, 15, 12))
+    dev = "cuda"
+    up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)      # noqa: E731
+    nsym, cz = g["height"] * g["width"], g["channels"]
+    words, off = up(g["words"].view(np.int16), np.int16), up(g["off"], np.int32)
+    for case in ("good", "bad_table", "short_stream"):
+        freq = g["freq"].copy()
+        lens = g["len"].copy()
+        if case == "bad_table":
+            freq[0] -= 1                                        # sums to 2^pb - 1: slot 2^pb - 1 has no symbol
+        elif case == "short_stream":
+            lens[1] = 2                                         # stream 1 holds only its initial state: it runs dry within ~10 symbols
+        out = torch.full((cz, nsym), 7.0, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        a = A.RansDecodeArgs(words.data_ptr(), off.data_ptr(), up(lens, np.int32).data_ptr(), up(freq.view(np.int16), np.int16).data_ptr(),
+                             cz, nsym, 2 * g["qmax"] + 1, g["prob_bits"], g["qmax"], g["step"], out.data_ptr(), None, status.data_ptr())
+        A.call("rans_decode_i16", a, None, 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        want = torch.from_numpy(q.reshape(cz, nsym).astype(np.float32) * np.float32(0.5)).to(dev)
+        assert int(status.item()) == (0 if case == "good" else 1), case
+        assert torch.isfinite(out).all()
+        if case == "good":
+            assert torch.equal(out, want)
+        elif case == "bad_table":
+            assert (out == 0).all()                             # nothing decoded
+        else:
+            assert torch.equal(out[0], want[0])                 # the intact stream is decoded in full
+            assert (out[1, 64:] == 0).all() and torch.equal(out[1, :2], want[1, :2])      # the short one stopped early, zero-filled
+    with pytest.raises(ValueError, match="no containers"):
+        cdx_mod.LatentDecoder()([])
+
+
 def test_bytes_to_image_chain_vs_oracle(cdx_mod, record):
     """bitstream -> rANS decode -> context net -> 6 DDIM steps, HIP vs the oracle chain: both PSNR gates."""
     ucfg = cdx_mod.unet_config(image_size=64, base_channels=32, channel_mult=(1, 2), attn_resolutions=(32,), num_res_blocks=1)

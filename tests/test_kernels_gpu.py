@@ -277,7 +277,8 @@ def test_attention_peaked_rows(cdx_mod):
 
 # ------------------------------------------------------------------ linear / temb
 @pytest.mark.parametrize("M,N,K,silu", [(16, 512, 128, False), (16, 512, 512, True), (1, 1000, 256, True), (3, 37, 64, False), (64, 64, 256, True),
-                                         (33, 200, 512, True), (64, 8704, 512, True), (128, 96, 768, True), (100, 130, 1024, False)])   # M > 32: row blocks (grid.y)
+                                         (33, 200, 512, True), (64, 8704, 512, True), (128, 96, 768, True), (100, 130, 1024, False),   # M > 32: row blocks (grid.y)
+                                         (20, 70, 1280, True), (3, 130, 2052, False), (17, 64, 4096, True)])   # K > 1024: slabs (temb_dim of base_channels > 256)
 def test_linear(cdx_mod, M, N, K, silu):
     x, w, b = rnd(M, K, seed=30), rnd(N, K, seed=31, scale=1 / math.sqrt(K)), rnd(N, seed=32)
     xin = F.silu(x.double()) if silu else x.double()
