@@ -86,7 +86,8 @@ def test_device_refuses_a_bad_frequency_table_and_stops_on_a_short_stream(cdx_mo
             lens[1] = 2                                         # stream 1 holds only its initial state: it runs dry within ~10 symbols
         out = torch.full((cz, nsym), 7.0, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-        a = A.RansDecodeArgs(words.data_ptr(), off.data_ptr(), up(lens, np.int32).data_ptr(), up(freq.view(np.int16), np.int16).data_ptr(),
+        d_len, d_freq = up(lens, np.int32), up(freq.view(np.int16), np.int16)      # (held: a temporary's block would be reused at once)
+        a = A.RansDecodeArgs(words.data_ptr(), off.data_ptr(), d_len.data_ptr(), d_freq.data_ptr(),
                              cz, nsym, 2 * g["qmax"] + 1, g["prob_bits"], g["qmax"], g["step"], out.data_ptr(), None, status.data_ptr())
         A.call("rans_decode_i16", a, None, 0, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
