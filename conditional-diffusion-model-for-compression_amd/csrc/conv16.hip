@@ -76,13 +76,18 @@ int conv16_dispatch(int ks, int stride, int logtw, bool bf, const Conv16Params& 
             case 3: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 3>>(p, stream);
             case 4: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 4>>(p, stream);
             case 7: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 7>>(p, stream);
+            case 5: return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 0, 1, 0, 1>>(p, stream);      // wave-specialised: 4 MFMA + 4 producer waves
+            case 6: return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 2048, 0, 1, 0, 1>>(p, stream);   // ... with round 2's loader (timing only)
             default: return CDX_ENOTSUP;
         }
     }
 #endif
     if (bf) return conv16_dispatch_bf16(ks, stride, logtw, p, stream);      // conv16_bf16.hip
+    // 3x3 at >= 32 pixels wide: the wave-specialised workgroup (4 MFMA + 4 producer waves, conv16_kernel.h WS): with one MFMA per
+    // (tap, 16 channels, M-tile) the staging arithmetic was 40 % of the 4-wave kernel -- +7...14 % in-process (profiles/r03_*)
+    if (ks == 3 && stride == 1 && logtw == 5) return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 0, 1, 0, 1>>(p, stream);
 #define C16(KS, ST, LT, MT) if (ks == KS && stride == ST && logtw == LT) return conv16_launch<Conv16Cfg<KS, ST, LT, MT>>(p, stream);
-    C16(3, 1, 2, 4) C16(3, 1, 3, 2) C16(3, 1, 4, 2) C16(3, 1, 5, 4)
+    C16(3, 1, 2, 4) C16(3, 1, 3, 2) C16(3, 1, 4, 2)
     C16(1, 1, 2, 4) C16(1, 1, 3, 2) C16(1, 1, 4, 2) C16(1, 1, 5, 4)
     C16(3, 2, 2, 2) C16(3, 2, 3, 2) C16(3, 2, 4, 2) C16(3, 2, 5, 2)
 #undef C16

@@ -5,8 +5,9 @@
 
 namespace cdx {
 int conv16_dispatch_bf16(int ks, int stride, int logtw, const Conv16Params& p, hipStream_t stream) {
+    if (ks == 3 && stride == 1 && logtw == 5) return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 0, 1, 1, 1>>(p, stream);      // wave-specialised (conv16.hip)
 #define C16(KS, ST, LT, MT) if (ks == KS && stride == ST && logtw == LT) return conv16_launch<Conv16Cfg<KS, ST, LT, MT, 3, 0, 0, 1, 1>>(p, stream);
-    C16(3, 1, 2, 4) C16(3, 1, 3, 2) C16(3, 1, 4, 2) C16(3, 1, 5, 4)
+    C16(3, 1, 2, 4) C16(3, 1, 3, 2) C16(3, 1, 4, 2)
     C16(1, 1, 2, 4) C16(1, 1, 3, 2) C16(1, 1, 4, 2) C16(1, 1, 5, 4)
     C16(3, 2, 2, 2) C16(3, 2, 3, 2) C16(3, 2, 4, 2) C16(3, 2, 5, 2)
 #undef C16

@@ -112,12 +112,11 @@ __device__ __forceinline__ unsigned amax_words(const unsigned* base, int b) {
     for (int k = 1; k < 16; ++k) m = v[k] > m ? v[k] : m;
     return m;
 }
-// one wave's contribution to amax_out: word chosen by `salt` (wave-global index).  The word only grows: most waves find a
-// larger value already there and skip the atomic; a stale read can only cause a redundant atomic, never a wrong maximum.
+// one wave's contribution to amax_out: word chosen by `salt` (wave-global index), fire-and-forget.  (A read of the word first,
+// to skip atomics that cannot raise it, made every wave END with a dependent load: +25 % on the short stride-2 launches in the
+// forward, where the words start at zero; the atomics themselves overlap with the rest of the launch.)
 __device__ __forceinline__ void amax_publish(unsigned* amax_out, int b, unsigned salt, float am) {
-    unsigned* w = amax_out + (size_t)b * CDX_AMAX_WORDS + (salt & (CDX_AMAX_WORDS - 1));
-    const unsigned bits = __float_as_uint(am);
-    if (bits > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, bits);
+    if (am != 0.f) atomicMax(amax_out + (size_t)b * CDX_AMAX_WORDS + (salt & (CDX_AMAX_WORDS - 1)), __float_as_uint(am));
 }
 template <bool SPLIT, bool GN>
 __device__ __forceinline__ ActScale act_scale_of(const Conv16Params& p, int b) {
@@ -156,10 +155,17 @@ __host__ __device__ inline bool conv16_tail_2x2(int cout, int mt) { const int re
 // DB = 0: ONE halo image and two barriers per chunk (stride-2 SPLIT tiles, whose 5 x 65-pixel hi|lo image would
 // otherwise leave room for a single workgroup per CU).
 // BF = 1: bfloat16 storage and v_mfma_f32_32x32x16_bf16 (dtype "bf16"); never together with SPLIT (fp16 hi | lo).
-template <int KS_, int STRIDE_, int LOGTW_, int MT_, int PF_ = 3, int ABL_ = 0, int SPLIT_ = 0, int DB_ = 1, int BF_ = 0>
+// WS = 1: WAVE-SPECIALISED workgroup of 8 waves (512 threads): waves 0-3 are the MFMA waves of the 4-wave layout (LDS operand
+// reads, weight ring, MFMAs, accumulator init, epilogue -- no staging arithmetic at all), waves 4-7 are PRODUCERS (halo loads,
+// GroupNorm / SiLU / split, LDS stores of the next chunk -- no MFMA); hand-off through the same two halo images and the same
+// one barrier per chunk.  The matrix pipe of a SIMD then never waits behind its own wave's vector work (round 2 measured
+// SQ_VALU_MFMA_COEXEC = 0.235 of the busy cycles with homogeneous waves).  Two such workgroups per CU = 4 waves per SIMD:
+// 128 VGPRs per wave, which the MFMA waves meet because the staging registers are gone.
+template <int KS_, int STRIDE_, int LOGTW_, int MT_, int PF_ = 3, int ABL_ = 0, int SPLIT_ = 0, int DB_ = 1, int BF_ = 0, int WS_ = 0>
 struct Conv16Cfg {
-    static constexpr int KS = KS_, STRIDE = STRIDE_, LOGTW = LOGTW_, MT = MT_, PF = PF_, ABL = ABL_, SPLIT = SPLIT_, DB = DB_, BF = BF_;
+    static constexpr int KS = KS_, STRIDE = STRIDE_, LOGTW = LOGTW_, MT = MT_, PF = PF_, ABL = ABL_, SPLIT = SPLIT_, DB = DB_, BF = BF_, WS = WS_;
     static_assert(!(SPLIT && BF), "the split operands are fp16");
+    static_assert(!WS || DB, "the producer waves fill the OTHER halo image");
     using H = std::conditional_t<BF != 0, __bf16, _Float16>;
     static constexpr int PLANES = SPLIT ? 2 : 1;                   // hi | lo
     static constexpr int KC = 32, PSH = KC * PLANES + 8;           // pixel stride in halves (80 B / 144 B)
@@ -202,7 +208,8 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     static_assert(C::MT % WM == 0 && (MT * 32) % C::TW == 0, "a wave's M-tiles must be whole tile rows");
     constexpr int PF = C::PF < GPC ? C::PF : GPC;
 
-    const int tid = threadIdx.x;
+    const int tid = C::WS ? (int)(threadIdx.x & 255u) : (int)threadIdx.x;      // WS: index inside the role's 4 waves
+    const bool producer = C::WS && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;      // wave-uniform
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wv % WN, wm = wv / WN;
@@ -261,11 +268,11 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     // Halo loads use buffer addressing: per-lane byte offset voff[i] = (pixel * channels + 8 q) * elem (one 32-bit VGPR per
     // pass, recomputed only when the chunk sequence moves from src0 to src1), scalar offset = chunk * 32 channels * elem.
     // hipcc's flat form spent ~25 VALU instructions of 64-bit address arithmetic per load (a 200-instruction clump per chunk).
-    // The resource covers IMAGE b of the source only (the host checks that one image is below 2 GiB, so 32-bit offsets
-    // cannot wrap whatever the batch): padding pixels and channel octets past the source's end get the offset kOOB >= any
-    // resource size -- the hardware returns 0 for them, so un-normalised staging needs no select, and NaN / Inf of
-    // neighbouring data cannot leak into padding.
-    constexpr unsigned kOOB = 0x80000000u;
+    // The resource covers IMAGE b of the source only (the host checks that one image is below 2 GiB, so 32-bit offsets cannot
+    // wrap whatever the batch).  Padding pixels, slots past the halo's last pixel and channel octets past the source's end
+    // read pixel 0 of the image -- an IN-RANGE dummy: out-of-range lanes are not free on this chip (with offsets beyond the
+    // resource for them the fp16 3x3 kernel measured 8 % slower, in-process A/B) -- and are zeroed by one select per value
+    // after the activation, so neither GroupNorm's shift nor NaN / Inf in the dummy can leak into the padding.
     unsigned voff[NPASS];
     __amdgpu_buffer_rsrc_t srs;
     int cur_src = -1;
@@ -275,7 +282,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         const size_t img = (size_t)p.Hin * p.Win * cs * esz;
         srs = buf_rsrc(static_cast<const char*>(p.src[sidx]) + (size_t)b * img, (unsigned)img);
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) voff[i] = ((vmask >> i) & 1u) ? ((unsigned)soff[i] * cs + 8u * (unsigned)q) * esz : kOOB;
+        for (int i = 0; i < NPASS; ++i) voff[i] = ((unsigned)soff[i] * cs + 8u * (unsigned)q) * esz;      // (soff = 0 for invalid slots)
         cur_src = sidx;
     };
     auto issue_loads = [&](int chunk) {
@@ -291,9 +298,8 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             const bool hi = C::SPLIT || cl + 8 <= cs;
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) {
-                const unsigned vo = cvalid ? voff[i] : kOOB;
-                const f32x4 v0 = buf_load4(srs, vo, so);
-                const f32x4 v1 = buf_load4(srs, vo + 16u, so);
+                const f32x4 v0 = buf_load4(srs, voff[i], so);
+                const f32x4 v1 = buf_load4(srs, voff[i] + 16u, so);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     pre[i][e] = v0[e];
@@ -303,7 +309,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         } else {
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) {
-                const h8 v = __builtin_bit_cast(h8, buf_load4(srs, cvalid ? voff[i] : kOOB, so));
+                const h8 v = __builtin_bit_cast(h8, buf_load4(srs, voff[i], so));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pre[i][e] = (float)v[e];
             }
@@ -329,9 +335,9 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     unsigned uo[EPU / 2], uol[EPU / 2];               // the unit being computed: packed 16-bit pairs (hi | lo)
     auto unit_pair = [&](int u, int kp) {             // channels 2 kp, 2 kp + 1 of unit u
         const int i = u / UPP, e = EPU * (u % UPP) + 2 * kp;
-        // padding pixels / channels past the source were LOADED as 0 (kOOB); only GroupNorm's shift makes them non-zero again,
-        // and they must be zero AFTER the activation: one select per value there.  No clamp: NaN / Inf and values beyond the
-        // fp16 range (impossible for finite inputs under the range contract) propagate as non-finite outputs, as F.conv2d's do.
+        // padding pixels / channels past the source hold a dummy read: they must be zero AFTER the activation -- one select per value.
+        // No clamp: NaN / Inf and values beyond the fp16 range (impossible for finite inputs under the range contract) propagate
+        // as non-finite outputs, as F.conv2d's do.
         const bool ok = cvalid && ((vmask >> i) & 1u);
         float v[2];
 #pragma unroll
@@ -340,7 +346,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             if constexpr (kGN) v[k] = fmaf(v[k], gsc[(e + k) >> 2][(e + k) & 3], gsh[(e + k) >> 2][(e + k) & 3]);
             else if constexpr (C::SPLIT) v[k] *= asc.a;
             if constexpr (kSILU) v[k] = silu16_f(v[k], asc.ksilu);
-            if constexpr (kGN) v[k] = ok ? v[k] : 0.f;
+            v[k] = ok ? v[k] : 0.f;
         }
         if constexpr (C::BF) {
             using b2 = __attribute__((ext_vector_type(2))) __bf16;
@@ -383,6 +389,26 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
 #pragma unroll
         for (int h = 0; h < UPP; ++h) write_unit(lds, UPP * i + h);
     };
+
+    if constexpr (C::WS) {
+        if (producer) {      // ---- producer waves: stage every chunk, one barrier per chunk in step with the MFMA waves ----
+            issue_loads(0);
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
+            if (p.nchunks > 1) issue_loads(1);
+            __syncthreads();
+            for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+                H* nxt = lds_all + ((chunk + 1) & 1) * C::LDS_HALVES;
+                if (chunk + 1 < p.nchunks) {
+#pragma unroll
+                    for (int i = 0; i < NPASS; ++i) write_pass(nxt, i);
+                    if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
+                }
+                __syncthreads();
+            }
+            return;
+        }
+    }
 
     // ---- MFMA operand addressing ----
     const int li = lane & 31, lh = lane >> 5;
@@ -464,11 +490,13 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     constexpr int NU = UPP * NPASS;
     constexpr int G0 = GPC > NU + 1 ? GPC - NU - 1 : 0;
     static_assert(NU + 1 <= GPC || GPC <= 2 || !C::DB, "staging units must fit in the chunk's groups (1x1: done after the groups)");
-    issue_loads(0);
-    stamp(1);
+    if constexpr (!C::WS) {
+        issue_loads(0);
+        stamp(1);
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
-    if (p.nchunks > 1 && !(C::ABL & 2)) issue_loads(1);
+        for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
+        if (p.nchunks > 1 && !(C::ABL & 2)) issue_loads(1);
+    }
     __syncthreads();
     stamp(2);
     h8 a[MT], al[MT];
@@ -483,7 +511,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         const H* lds = lds_all + (C::DB ? (chunk & 1) * C::LDS_HALVES : 0);
         H* nxt = lds_all + (C::DB ? ((chunk + 1) & 1) * C::LDS_HALVES : 0);
         const bool more = chunk + 1 < p.nchunks && !(C::ABL & 2);
-        if (C::DB && (!nvalid || GPC <= 2)) {
+        if (!C::WS && C::DB && (!nvalid || GPC <= 2)) {
             // a wave without output channels (or a 1x1 layer: two groups per chunk) stages in one go
             if (more) {
 #pragma unroll
@@ -503,9 +531,9 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                 constexpr bool kInterleave = C::DB && GPC > 2 && NM >= 4 && !(C::ABL & 128);
                 // (compile-time: in the LAST chunk the unit restages stale registers into the idle image -- harmless, and it
                 // keeps the unrolled chunk body free of runtime branches, which would cut it into small scheduling regions)
-                const bool stage_here = C::DB && GPC > 2 && !(C::ABL & 2) && g >= G0 && g < G0 + NU;
+                const bool stage_here = !C::WS && C::DB && GPC > 2 && !(C::ABL & 2) && g >= G0 && g < G0 + NU;
                 if (stage_here && !kInterleave) write_unit(nxt, g - G0);
-                if (C::DB && GPC > 2 && more && g == G0 + NU && chunk + 2 < p.nchunks && !(C::ABL & 64)) issue_loads(chunk + 2);
+                if (!C::WS && C::DB && GPC > 2 && more && g == G0 + NU && chunk + 2 < p.nchunks && !(C::ABL & 64)) issue_loads(chunk + 2);
                 const int tap = g >> 1, j = g & 1, ky = tap / C::KS, kx = tap % C::KS;
                 int ab = a_base;
                 asm volatile("" : "+v"(ab));                 // no cross-tap CSE of LDS reads (see conv_kernel.h)
@@ -825,6 +853,48 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
         }
     }
     conv16_body<C, STG, 1>(p, lds_all);
+}
+
+// wave-specialised form: 8 waves, two workgroups per CU = 4 waves per SIMD (<= 128 VGPRs)
+template <class C, int STG>
+__global__ __launch_bounds__(512, 4) void conv16_ws_kernel(const Conv16Params p) {
+    static_assert(C::WS && C::DB, "conv16_ws_kernel runs the WS configurations");
+    __shared__ __attribute__((aligned(16))) typename C::H lds_all[2 * C::LDS_HALVES];
+    if constexpr (C::MT == 4) {
+        if (blockIdx.y == gridDim.y - 1 && conv16_tail_2x2(p.Cout, C::MT)) {
+            conv16_body<C, STG, 2>(p, lds_all);
+            return;
+        }
+    }
+    conv16_body<C, STG, 1>(p, lds_all);
+}
+
+#ifdef CDX_TUNING
+#include <stdlib.h>
+// tuning build only: CDX_NO_WS=1 routes the wave-specialised launches to the 4-wave kernel of the same configuration (same-box
+// A/B of whole bench runs: tools/session/gpu_r3h.sh)
+inline bool ws_disabled() {
+    static const bool off = [] { const char* e = getenv("CDX_NO_WS"); return e && e[0] == '1'; }();
+    return off;
+}
+#endif
+
+template <class C>
+inline int conv16_launch(const Conv16Params& p, hipStream_t stream);
+
+template <class C>
+inline int conv16_ws_launch(const Conv16Params& p, hipStream_t stream) {
+#ifdef CDX_TUNING
+    if (ws_disabled()) return conv16_launch<Conv16Cfg<C::KS, C::STRIDE, C::LOGTW, C::MT, C::PF, C::ABL, C::SPLIT, C::DB, C::BF, 0>>(p, stream);
+#endif
+    dim3 grid(p.tiles_x * p.tiles_y * p.B, ceil_div(p.Cout, C::BN));
+    switch (p.gn ? (p.silu ? 2 : 1) : (p.silu ? 3 : 0)) {
+        case 0: hipLaunchKernelGGL((conv16_ws_kernel<C, 0>), grid, dim3(512), 0, stream, p); break;
+        case 1: hipLaunchKernelGGL((conv16_ws_kernel<C, 1>), grid, dim3(512), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((conv16_ws_kernel<C, 2>), grid, dim3(512), 0, stream, p); break;
+        default: hipLaunchKernelGGL((conv16_ws_kernel<C, 3>), grid, dim3(512), 0, stream, p); break;
+    }
+    return check_launch();
 }
 
 template <class C>

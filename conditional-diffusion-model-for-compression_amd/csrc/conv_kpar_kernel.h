@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
     float pre[NPASS][8];
     f32x4 gsc[2], gsh[2];
     bool cvalid = false;
-    // per-image buffer resource; padding pixels / channel octets past the source's end load as 0 (offset kOOB): conv16_kernel.h
-    constexpr unsigned kOOB = 0x80000000u;
+    // per-image buffer resource; padding pixels / slots past the halo / channel octets past the source's end read pixel 0 (in range)
+    // and are zeroed by a select after the activation: conv16_kernel.h
     unsigned voff[NPASS];
     __amdgpu_buffer_rsrc_t srs;
     int cur_src = -1;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
         const size_t img = (size_t)p.Hin * p.Win * cs * ES;
         srs = buf_rsrc(static_cast<const char*>(p.src[sidx]) + (size_t)b * img, (unsigned)img);
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) voff[i] = ((vmask >> i) & 1u) ? ((unsigned)soff[i] * cs + 8u * (unsigned)q) * ES : kOOB;
+        for (int i = 0; i < NPASS; ++i) voff[i] = ((unsigned)soff[i] * cs + 8u * (unsigned)q) * ES;      // (soff = 0 for invalid slots)
         cur_src = sidx;
     };
     auto issue_loads = [&](int chunk) {
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
         const unsigned so = (unsigned)cc * (unsigned)KC * ES;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            const unsigned vo = cvalid ? voff[i] : kOOB;
+            const unsigned vo = voff[i];
             if constexpr (C::SPLIT) {
                 const f32x4 v0 = buf_load4(srs, vo, so), v1 = buf_load4(srs, vo + 16u, so);
 #pragma unroll
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
     auto stage_pass = [&](int i) {                                 // GroupNorm / SiLU / saturate / split, one pixel slot x 8 channels
         const int hp = i * 16 + pl;
         const int hy = hp / C::HW, hx = hp - hy * C::HW;
-        const bool ok = cvalid && ((vmask >> i) & 1u);            // (padding loads as 0: only GroupNorm's shift needs the select)
+        const bool ok = cvalid && ((vmask >> i) & 1u);            // (padding holds a dummy read: zeroed after the activation)
         using u4 = __attribute__((ext_vector_type(4))) unsigned;
         u4 o, ol;
 #pragma unroll
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
                 if constexpr (kGN) v[k] = fmaf(v[k], gsc[(e + k) >> 2][(e + k) & 3], gsh[(e + k) >> 2][(e + k) & 3]);
                 else if constexpr (C::SPLIT) v[k] *= asc.a;
                 if constexpr (kSILU) v[k] = silu16_f(v[k], asc.ksilu);
-                if constexpr (kGN) v[k] = ok ? v[k] : 0.f;
+                v[k] = ok ? v[k] : 0.f;
             }
             if constexpr (C::BF) {
                 using b2 = __attribute__((ext_vector_type(2))) __bf16;

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "conv_kpar_kernel.h"
+#include "conv_wsp_kernel.h"
 
 using namespace cdx;
 
@@ -63,6 +64,16 @@ extern "C" int cdx_conv_pack_weights_split_f16(const float* w, int32_t c0, int32
 }
 
 namespace cdx {
+// CUs of the current device: the persistent kernel launches one workgroup per CU (queried once; every GPU of a node is the same part)
+int wsp_cu_count() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus;
+    }();
+    return n;
+}
+
 // Is this cdx_conv_f32 launch one the SPLIT kernel is built for?  (conv.hip asks before choosing the tile.)
 bool conv_split_ok(const cdx_conv_args* a) {
     if (!a->wpacked_split || !aligned16(a->wpacked_split) || !(a->wsplit_unscale > 0.f)) return false;
@@ -135,12 +146,20 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
         return conv_kpar_launch<KparCfg<1, 3>>(p, stream);
     }
 #ifdef CDX_TUNING
+    if (a->ksize == 1 && variant == 40) return conv16_ws_launch<Conv16Cfg<1, 1, 5, 4, 3, 0, 1, 1, 0, 1>>(p, stream);
+    if (a->ksize == 3 && variant == 46) return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 1>>(p, stream);      // the 4-wave tile (round 2's product)
     if (a->ksize == 3 && variant) {      // timing ablations / tuning variants (tools/conv_bench.py --tiles 60..)
         if (variant >= 100) {            // + 100: the same variant (100 = the shipped tile) at ONE workgroup per CU (solo waves)
             p.abl = 1024;
             variant -= 100;
         }
         switch (variant) {
+            case 42: return conv_wsp_launch<WspCfg<3>>(p, stream);      // persistent wave-specialised (4 sum slots per tile)
+            case 43: return conv_wsp_launch<WspCfg<3, 1>>(p, stream);   // ... MFMA waves' own bound
+            case 44: return conv_wsp_launch<WspCfg<3, 2>>(p, stream);   // ... producers' own bound
+            case 45: return conv_wsp_launch<WspCfg<3, 5>>(p, stream);   // ... MFMA waves without weight refills
+            case 40: return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 1, 1, 0, 1>>(p, stream);      // wave-specialised: 4 MFMA + 4 producer waves
+            case 41: return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 2, 0, 1, 1, 0, 1>>(p, stream);      // ... ring depth 2
             case 0: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 1>>(p, stream);
             case 1: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 1, 1>>(p, stream);      // no epilogue
             case 2: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 2, 1>>(p, stream);      // stage first chunk only
@@ -164,7 +183,10 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
         }
     }
 #endif
-    if (a->ksize == 3) return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 1>>(p, stream);
+    // 3x3 at >= 32 pixels wide (79 % of the cfg2 step): the WAVE-SPECIALISED workgroup -- 4 MFMA waves + 4 producer waves
+    // (conv16_kernel.h WS): bit-identical to the 4-wave tile, +3...5 % (in-process A/B, profiles/r03_*); the HBM-bound 1x1
+    // layers gain nothing from it and keep the 4-wave form
+    if (a->ksize == 3) return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 1, 1, 0, 1>>(p, stream);
     return conv16_launch<Conv16Cfg<1, 1, 5, 4, 3, 0, 1>>(p, stream);
 }
 }  // namespace cdx
