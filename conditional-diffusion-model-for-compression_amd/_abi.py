@@ -30,7 +30,8 @@ class ConvArgs(C.Structure):
                 ("wpacked", _f), ("bias", _f), ("gn_scale", _f), ("gn_shift", _f),
                 ("temb", _f), ("temb_ld", _i), ("residual", _f), ("out", _f), ("out_ld", _i), ("wpacked_wino", _f), ("stats_out", _f),
                 ("wpacked_split", _f), ("wsplit_unscale", C.c_float), ("gn_exp", _i),
-                ("src_amax0", _f), ("src_amax1", _f), ("stats_slots", _i), ("amax_out", _f)]
+                ("src_amax0", _f), ("src_amax1", _f), ("wpacked_split_up", _f), ("wsplit_up_unscale", C.c_float * 4),
+                ("stats_slots", _i), ("amax_out", _f)]
 
 
 class ConvF16Args(C.Structure):
@@ -160,7 +161,7 @@ EXPORTS = (["cdx_abi_version", "cdx_strerror", "cdx_launch_count",
             "cdx_conv_packed_floats", "cdx_conv_pack_weights_f32", "cdx_conv_select_tile", "cdx_conv_f32_tile",
             "cdx_conv_stats_slots", "cdx_conv_wino_packed_floats", "cdx_conv_pack_weights_wino_f32",
             "cdx_conv_f16_stats_slots", "cdx_conv_f16_packed_halves", "cdx_conv_pack_weights_f16",
-            "cdx_conv_split_packed_halves", "cdx_conv_pack_weights_split_f16", "cdx_conv_pack_weights_bf16", "cdx_gn_act_exp"]
+            "cdx_conv_split_packed_halves", "cdx_conv_pack_weights_split_f16", "cdx_conv_split_up_packed_halves", "cdx_conv_pack_weights_split_up_f16", "cdx_conv_pack_weights_bf16", "cdx_gn_act_exp"]
            + [f"cdx_{op}" for op in OPS] + [f"cdx_{op}_workspace" for op in OPS])
 
 _lib = None
@@ -205,6 +206,10 @@ def lib() -> C.CDLL:
     L.cdx_conv_split_packed_halves.argtypes = [_i, _i, _i, _i]
     L.cdx_conv_pack_weights_split_f16.restype = C.c_int
     L.cdx_conv_pack_weights_split_f16.argtypes = [_f, _i, _i, _i, _i, _f, C.POINTER(C.c_float)]
+    L.cdx_conv_split_up_packed_halves.restype = C.c_size_t
+    L.cdx_conv_split_up_packed_halves.argtypes = [_i, _i, _i]
+    L.cdx_conv_pack_weights_split_up_f16.restype = C.c_int
+    L.cdx_conv_pack_weights_split_up_f16.argtypes = [_f, _i, _i, _i, _f, C.POINTER(C.c_float)]
     L.cdx_conv_select_tile.restype = C.c_int
     L.cdx_conv_select_tile.argtypes = [C.POINTER(ConvArgs)]
     L.cdx_conv_stats_slots.restype = C.c_int32
@@ -303,6 +308,22 @@ def pack_conv_weights_split(w_oihw, c0: int, c1: int):
     check(lib().cdx_conv_pack_weights_split_f16(w.ctypes.data, c0, c1, cout, k, out.ctypes.data, C.byref(un)),
           "cdx_conv_pack_weights_split_f16")
     return out, float(un.value)
+
+
+def pack_conv_weights_split_up(w_oihw, c0: int, c1: int):
+    """numpy OIHW 3x3 float32 -> (four fp16 hi|lo phase images back to back as numpy float16, [4] unscales): the four 2x2
+    convolutions that equal the 3x3 convolution after nearest-2x upsampling (cdx.h wpacked_split_up) (host)."""
+    import numpy as np
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    cout, cin, k, _ = w.shape
+    assert cin == c0 + c1 and k == 3
+    n = int(lib().cdx_conv_split_up_packed_halves(c0, c1, cout))
+    if n == 0:
+        raise CdxError("cdx_conv_split_up_packed_halves: bad arguments")
+    out = np.empty(n, np.float16)
+    un = (C.c_float * 4)()
+    check(lib().cdx_conv_pack_weights_split_up_f16(w.ctypes.data, c0, c1, cout, out.ctypes.data, un), "cdx_conv_pack_weights_split_up_f16")
+    return out, [float(v) for v in un]
 
 
 def pack_conv_weights_bf16(w_oihw, c0: int, c1: int):

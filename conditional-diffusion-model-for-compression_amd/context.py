@@ -196,7 +196,7 @@ class ContextNet:
         for name, shp in shapes.items():
             if name.endswith(".weight") and len(shp) == 4:
                 base = name[:-7]
-                self.convs[base] = ops.PackedConv(P[name], P[base + ".bias"], shp[1], 0, self.device, split=split)
+                self.convs[base] = ops.PackedConv(P[name], P[base + ".bias"], shp[1], 0, self.device, split=split, up=base.startswith("ctx.up"))
             elif ".norm" in name:
                 self.dev[name] = torch.from_numpy(np.ascontiguousarray(P[name])).to(self.device)
                 self.host[name] = P[name]

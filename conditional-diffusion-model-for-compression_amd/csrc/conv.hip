@@ -10,6 +10,7 @@ using namespace cdx;
 
 namespace cdx {
 bool conv_split_ok(const cdx_conv_args* a);                       // conv_split.hip
+bool conv_split_up_ok(const cdx_conv_args* a);
 int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant = 0);
 int conv_split_slots_per_tile(const cdx_conv_args* a);
 int amax_launch(const float* x, int x_ld, int batch, int n, int channels, unsigned* out, hipStream_t stream);   // range.hip
@@ -186,6 +187,7 @@ int validate(const cdx_conv_args* a) {
     CDX_REQUIRE(aligned16(a->src0) && aligned16(a->src1) && aligned16(a->wpacked));
     if (a->flags & CDX_CONV_GN) CDX_REQUIRE(a->gn_scale && a->gn_shift && aligned16(a->gn_scale) && aligned16(a->gn_shift));
     if (a->wpacked_split) CDX_REQUIRE(aligned16(a->wpacked_split) && a->wsplit_unscale > 0.f);
+    if (a->wpacked_split_up) CDX_REQUIRE(aligned16(a->wpacked_split_up) && a->wpacked_split != nullptr);
     CDX_REQUIRE(a->gn_exp >= -60 && a->gn_exp <= 60);
     if (!(a->flags & CDX_CONV_GN)) CDX_REQUIRE(a->gn_exp == 0);
     if (a->amax_out) CDX_REQUIRE((a->cout % 4) == 0 && (a->out_ld % 4) == 0 && aligned16(a->out));
@@ -209,6 +211,8 @@ extern "C" int cdx_conv_select_tile(const cdx_conv_args* a) {
 
 namespace {
 int slots_of(const cdx_conv_args* a, const Tile& t) {
+    // the four-phase form of an upsampled 3x3 layer tiles the LOW-resolution grid, once per phase
+    if (t.wcfg == WCFG_SPLIT && conv_split_up_ok(a)) return 4 * ceil_div(a->win, 32) * ceil_div(a->hin, 4) * t.wm;
     const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : a->wout >= 8 ? 3 : 2;
     const int tw = 1 << logtw, th = t.bm / tw;
     return ceil_div(a->wout, tw) * ceil_div(a->hout, th) * t.wm;

@@ -180,6 +180,7 @@ extern "C" int cdx_conv_f16(const cdx_conv_f16_args* a, void*, size_t, cdx_strea
     p.residual = a->residual;
     p.out = a->out; p.out_f32 = a->out_is_f32 ? 1 : 0; p.out_ld = a->out_ld; p.stats = a->stats_out;
     p.stats_wm = conv16_tail_2x2(a->cout, f16_mt(a)) ? 2 : 1;
+    p.ostep = 1; p.ody = p.odx = 0; p.pady = p.padx = a->ksize / 2; p.slot_base = 0; p.nslots_total = 0;
     p.act_exp = 0;
     p.amax[0] = p.amax[1] = nullptr;
     p.amax_out = nullptr;

@@ -84,6 +84,11 @@ struct Conv16Params {
     int tiles_x, tiles_y;
     // SPLIT range contract (cdx.h): the activation exponent comes from act_exp (GroupNorm-ed input: gscale / gshift arrive
     // pre-multiplied by 2^act_exp) or, per image, from the producers' amax words of the un-normalised sources
+    // PHASE launches of a 3x3 convolution after nearest-2x upsampling (conv_split.hip: four 2x2 convolutions on the LOW-resolution
+    // source, one per output phase (dy, dx); KS = 2): the tile walks low-resolution pixels (Hout x Wout), output pixel (y, x) of the
+    // launch is stored at (ostep y + ody, ostep x + odx) of the full-resolution tensor, the halo starts pady / padx pixels up / left
+    // of the tile, and the launch's GroupNorm-sum slots start at slot_base of nslots_total.  Plain launches: 1, 0, 0, PAD, PAD, 0, 0.
+    int ostep, ody, odx, pady, padx, slot_base, nslots_total;
     int act_exp;
     const unsigned* amax[2]; // [B][CDX_AMAX_WORDS] float32 bit patterns (max over the words = max |x| of the image) per source, or null
     unsigned* amax_out;      // [B][CDX_AMAX_WORDS] or null: atomic max of one word with the bit pattern of the wave's max |out|
@@ -221,7 +226,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     const int b = bx / p.tiles_y;
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
     const int oy0w = oy0 + ((wm * MT * 32) >> C::LOGTW);           // first output row of THIS wave's M-tiles
-    const int iy0 = oy0 * C::STRIDE - C::PAD, ix0 = ox0 * C::STRIDE - C::PAD;
+    const int iy0 = oy0 * C::STRIDE - (C::KS == 2 ? p.pady : C::PAD), ix0 = ox0 * C::STRIDE - (C::KS == 2 ? p.padx : C::PAD);
     // ABL & 512 (diagnostic build): s_memtime stamps per wave at the phase boundaries, 16 per wave, into the buffer behind
     // p.stats (which then holds no sums): 0 entry, 1 first loads issued, 2 first chunk staged (barrier passed), 3 + c chunk c
     // done (c < 8), 12 stores issued, 13 HW_ID, 14 XCC_ID  (digest: tools/conv_bench.py --stamps)
@@ -607,11 +612,13 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         // ~43 vector instructions per 16-byte store, 8 of them quarter-rate integer multiplies for the flat address.)
         constexpr int ROWS = (MT * 32) >> C::LOGTW;
         const bool full = oy0w + ROWS <= p.Hout && ox0 + C::TW <= p.Wout;          // wave-uniform
-        const size_t first = (((size_t)b * p.Hout + oy0w) * p.Wout + ox0) * p.out_ld;
-        const size_t left = ((size_t)p.B * p.Hout * p.Wout * p.out_ld - first) * 4;
+        // (phase launches: output pixel (y, x) lands at (os y + ody, os x + odx) of the os-times larger tensor; os = 1 otherwise)
+        const unsigned os = (unsigned)p.ostep, WoutF = (unsigned)p.Wout * os;
+        const size_t first = (((size_t)b * p.Hout * os + (size_t)oy0w * os + p.ody) * WoutF + (size_t)ox0 * os + p.odx) * p.out_ld;
+        const size_t left = ((size_t)p.B * p.Hout * os * WoutF * p.out_ld - first) * 4;
         constexpr unsigned kDrop = 0x80000000u;                                    // beyond any resource: the store is dropped
         const __amdgpu_buffer_rsrc_t ors = buf_rsrc(static_cast<float*>(p.out) + first, left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)left);
-        const unsigned vbase = nok ? ((unsigned)(4 * lh) * (unsigned)p.out_ld + (unsigned)n) * 4u : kDrop;
+        const unsigned vbase = nok ? ((unsigned)(4 * lh) * os * (unsigned)p.out_ld + (unsigned)n) * 4u : kDrop;
         float un = asc.un;
         if (asc.late) {                              // (rare: see ActScale) outputs first, then the additive terms at their own scale
             add_terms(std::false_type{}, un, 1.f);   // (lanes without an output channel keep raw accumulators: never stored)
@@ -628,7 +635,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                 for (int r = 0; r < 16; ++r) {
                     const int mb = t * 32 + 8 * (r >> 2) + (r & 3);
                     const int row = mb >> C::LOGTW, col = mb & (C::TW - 1);
-                    const unsigned soff = ((unsigned)row * (unsigned)p.Wout + (unsigned)col) * (unsigned)p.out_ld * 4u;
+                    const unsigned soff = ((unsigned)row * os * WoutF + (unsigned)col * os) * (unsigned)p.out_ld * 4u;
                     const float x = acc[t][r] * un;
                     bool ok = true;
                     if constexpr (!decltype(full_)::value) ok = oy0w + row < p.Hout && ox0 + col + 4 * lh < p.Wout;
@@ -651,8 +658,8 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             s1 += __shfl_xor(s1, 32);                  // the two lane halves hold different pixels of the same channel
             s2 += __shfl_xor(s2, 32);
             if (lh == 0 && nok) {
-                const int slot = (ty * p.tiles_x + tx) * p.stats_wm + (WM == 2 ? wm : 0);
-                const int nslots = p.tiles_y * p.tiles_x * p.stats_wm;
+                const int slot = p.slot_base + (ty * p.tiles_x + tx) * p.stats_wm + (WM == 2 ? wm : 0);
+                const int nslots = p.nslots_total ? p.nslots_total : p.tiles_y * p.tiles_x * p.stats_wm;
                 double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + n) * 2;
                 o[0] = s1;
                 o[1] = s2;

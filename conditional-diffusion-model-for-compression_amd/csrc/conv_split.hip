@@ -2,6 +2,7 @@
 // operands, reached through cdx_conv_f32 (conv.hip selects it as CDX_TILE_SPLIT).  Host packer + launch.
 // (A translation unit of its own: the kernel template is instantiated ~50 times here and in conv16.hip.)
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "conv_kpar_kernel.h"
@@ -24,14 +25,14 @@ extern "C" size_t cdx_conv_split_packed_halves(int32_t c0, int32_t c1, int32_t c
     return ntiles * nch * ksize * ksize * 2048 + 8192;
 }
 
-extern "C" int cdx_conv_pack_weights_split_f16(const float* w, int32_t c0, int32_t c1, int32_t cout, int32_t ksize,
-                                               cdx_half* packed, float* unscale) {
-    CDX_REQUIRE(w && packed && unscale && c0 > 0 && c1 >= 0 && cout > 0 && (ksize == 1 || ksize == 3));
+namespace {
+// fp16 hi | lo fragment image of OIHW weights with a k x k kernel (k = 1, 2, 3), scaled by the power of two that puts max |w| in [2^13, 2^14)
+int pack_split(const float* w, int c0, int c1, int cout, int ksize, _Float16* o, float* unscale) {
     const int taps = ksize * ksize, ctot = c0 + c1;
     const int nch0 = chunks_of(c0), nch = nch0 + chunks_of(c1), ntiles = (cout + 31) / 32;
     float wmax = 0.f;
     for (size_t i = 0; i < (size_t)cout * ctot * taps; ++i) {
-        CDX_REQUIRE(w[i] == w[i] && w[i] - w[i] == 0.f);      // finite
+        if (!(w[i] == w[i] && w[i] - w[i] == 0.f)) return CDX_EINVAL;      // finite
         wmax = fmaxf(wmax, fabsf(w[i]));
     }
     int e = 0;
@@ -43,7 +44,6 @@ extern "C" int cdx_conv_pack_weights_split_f16(const float* w, int32_t c0, int32
     }
     const float sc = ldexpf(1.f, e);
     *unscale = ldexpf(1.f, -e);
-    _Float16* o = reinterpret_cast<_Float16*>(packed);
     for (int nt = 0; nt < ntiles; ++nt)
         for (int ch = 0; ch < nch; ++ch)
             for (int tap = 0; tap < taps; ++tap)
@@ -61,6 +61,50 @@ extern "C" int cdx_conv_pack_weights_split_f16(const float* w, int32_t c0, int32
                             }
     memset(o, 0, 8192 * sizeof(_Float16));
     return CDX_OK;
+}
+}  // namespace
+
+extern "C" int cdx_conv_pack_weights_split_f16(const float* w, int32_t c0, int32_t c1, int32_t cout, int32_t ksize,
+                                               cdx_half* packed, float* unscale) {
+    CDX_REQUIRE(w && packed && unscale && c0 > 0 && c1 >= 0 && cout > 0 && (ksize == 1 || ksize == 3));
+    return pack_split(w, c0, c1, cout, ksize, reinterpret_cast<_Float16*>(packed), unscale);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// 3x3 convolution AFTER nearest-2x upsampling = four 2x2 convolutions on the LOW-resolution source, one per output phase
+// (dy, dx): output row 2y + dy reads upsampled rows 2y + dy - 1 + ky, i.e. source rows y - 1, y, y (dy = 0) or y, y, y + 1
+// (dy = 1) -- taps that read the same source pixel merge: K(0,0) = {0}, K(0,1) = {1, 2}, K(1,0) = {0, 1}, K(1,1) = {2} per axis.
+// 16 tap-passes over N_lo pixels instead of 9 over 4 N_lo: 2.25x fewer MFMAs, and the source is read at low resolution.
+// The merged weights are summed in float64 and rounded once to float32 before the hi | lo split (a different rounding of the
+// same sum as F.conv2d's: the tolerance does not move).  Image: [phase = 2 dy + dx][ksize-2 split image], unscale per phase.
+extern "C" size_t cdx_conv_split_up_packed_halves(int32_t c0, int32_t c1, int32_t cout) {
+    if (c0 <= 0 || c1 < 0 || cout <= 0) return 0;
+    const size_t ntiles = (cout + 31) / 32, nch = chunks_of(c0) + chunks_of(c1);
+    return 4 * (ntiles * nch * 4 * 2048 + 8192);
+}
+
+extern "C" int cdx_conv_pack_weights_split_up_f16(const float* w, int32_t c0, int32_t c1, int32_t cout, cdx_half* packed, float* unscale4) {
+    CDX_REQUIRE(w && packed && unscale4 && c0 > 0 && c1 >= 0 && cout > 0);
+    const int ctot = c0 + c1;
+    const size_t per = cdx_conv_split_up_packed_halves(c0, c1, cout) / 4;
+    float* w2 = static_cast<float*>(malloc((size_t)cout * ctot * 4 * sizeof(float)));
+    CDX_REQUIRE(w2);
+    static const int klo[2][2] = {{0, 1}, {0, 2}}, khi[2][2] = {{0, 2}, {1, 2}};      // [d][t]: taps K(d, t) = klo .. khi
+    int rc = CDX_OK;
+    for (int dy = 0; dy < 2 && rc == CDX_OK; ++dy)
+        for (int dx = 0; dx < 2 && rc == CDX_OK; ++dx) {
+            for (size_t nc = 0; nc < (size_t)cout * ctot; ++nc)
+                for (int ty = 0; ty < 2; ++ty)
+                    for (int tx = 0; tx < 2; ++tx) {
+                        double acc = 0;
+                        for (int ky = klo[dy][ty]; ky <= khi[dy][ty]; ++ky)
+                            for (int kx = klo[dx][tx]; kx <= khi[dx][tx]; ++kx) acc += (double)w[nc * 9 + ky * 3 + kx];
+                        w2[nc * 4 + ty * 2 + tx] = (float)acc;
+                    }
+            rc = pack_split(w2, c0, c1, cout, 2, reinterpret_cast<_Float16*>(packed) + (size_t)(2 * dy + dx) * per, unscale4 + 2 * dy + dx);
+        }
+    free(w2);
+    return rc;
 }
 
 namespace cdx {
@@ -93,6 +137,14 @@ bool conv_split_ok(const cdx_conv_args* a) {
     return true;
 }
 
+// The four-phase form of an upsampled 3x3 layer (above): the phase image is given, the LOW-resolution rows hold a 32-pixel tile
+// row, no residual (the phase launches keep the plain accumulator init: an up-sampling layer has none in this model family)
+bool conv_split_up_ok(const cdx_conv_args* a) {
+    return (a->flags & CDX_CONV_UPSAMPLE2X) && a->ksize == 3 && a->stride == 1 && a->wpacked_split_up && aligned16(a->wpacked_split_up) &&
+           a->win >= 32 && !a->residual && a->wsplit_up_unscale[0] > 0.f && a->wsplit_up_unscale[1] > 0.f && a->wsplit_up_unscale[2] > 0.f &&
+           a->wsplit_up_unscale[3] > 0.f;
+}
+
 // GroupNorm-sum slots per spatial tile of a SPLIT launch: 2 when the 128-pixel tile's last channel block runs 2 x 2
 int conv_split_slots_per_tile(const cdx_conv_args* a) {
     if (a->stride == 1 && a->wout < 16) return 4;      // chunk-parallel tile (conv_kpar_kernel.h): one slot per finishing wave
@@ -120,6 +172,7 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     p.residual = a->residual;
     p.out = a->out; p.out_f32 = 1; p.out_ld = a->out_ld; p.stats = a->stats_out;
     p.stats_wm = conv_split_slots_per_tile(a);
+    p.ostep = 1; p.ody = p.odx = 0; p.pady = p.padx = a->ksize / 2; p.slot_base = 0; p.nslots_total = 0;
     p.act_exp = (a->flags & CDX_CONV_GN) ? a->gn_exp : 0;
     p.amax[0] = (a->flags & CDX_CONV_GN) ? nullptr : a->src_amax0;
     p.amax[1] = (a->flags & CDX_CONV_GN) || a->c1 == 0 ? nullptr : a->src_amax1;
@@ -127,6 +180,27 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     // tile: 128 pixels x 128 channels at >= 32 pixels wide; 64 x 128 for stride 2 and at 16 pixels wide; 64 pixels x 32
     // channels with the input chunks split over the waves at 8 pixels wide (conv_kpar_kernel.h: at batch 16 that level has
     // too few output pixels to fill 256 CUs with 128-channel tiles: 1.06 -> 0.49 ms per forward for its 3x3 layers)
+    if (conv_split_up_ok(a)) {
+        // four phase launches over the LOW-resolution pixel grid (128-pixel x 128-channel wave-specialised tiles, 2 x 2 taps)
+        p.ups = 0;
+        p.Hout = a->hin; p.Wout = a->win;
+        p.tiles_x = ceil_div(a->win, 32);
+        p.tiles_y = ceil_div(a->hin, 4);
+        CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
+        p.ostep = 2;
+        p.nslots_total = 4 * p.tiles_x * p.tiles_y * p.stats_wm;
+        const size_t per = cdx_conv_split_up_packed_halves(a->c0, a->c1, a->cout) / 4;
+        for (int ph = 0; ph < 4; ++ph) {
+            p.ody = ph >> 1; p.odx = ph & 1;
+            p.pady = 1 - p.ody; p.padx = 1 - p.odx;
+            p.slot_base = ph * p.tiles_x * p.tiles_y * p.stats_wm;
+            p.w = a->wpacked_split_up + (size_t)ph * per;
+            p.wunscale = a->wsplit_up_unscale[ph];
+            const int rc = conv16_ws_launch<Conv16Cfg<2, 1, 5, 4, 2, 0, 1, 1, 0, 1>>(p, stream);
+            if (rc) return rc;
+        }
+        return CDX_OK;
+    }
     const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : 3, tw = 1 << logtw;
     const int bm = (a->stride == 2 || a->wout < 32) ? 64 : 128, th = bm / tw;
     p.tiles_x = ceil_div(a->wout, tw);
@@ -158,6 +232,7 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
             case 43: return conv_wsp_launch<WspCfg<3, 1>>(p, stream);   // ... MFMA waves' own bound
             case 44: return conv_wsp_launch<WspCfg<3, 2>>(p, stream);   // ... producers' own bound
             case 45: return conv_wsp_launch<WspCfg<3, 5>>(p, stream);   // ... MFMA waves without weight refills
+            case 47: return conv_wsp_launch<WspCfg<3, 8>>(p, stream);   // ... producers at s_setprio 3
             case 40: return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 1, 1, 0, 1>>(p, stream);      // wave-specialised: 4 MFMA + 4 producer waves
             case 41: return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 2, 0, 1, 1, 0, 1>>(p, stream);      // ... ring depth 2
             case 0: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 1>>(p, stream);

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(512, 2) void conv_wsp_kernel(const Conv16Params p, 
 
     if (producer) {
         // =================================================== producer waves ===================================================
+        if constexpr ((C::ABL & 8) != 0) __builtin_amdgcn_s_setprio(3);      // (experiment: producers win issue arbitration)
         const int q = tid & 3, pl = tid >> 2;
         const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
         // ---- loader state of the tile whose chunks are being LOADED ----

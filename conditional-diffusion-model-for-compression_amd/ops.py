@@ -41,7 +41,7 @@ def _ws(nbytes: int, device):
 class PackedConv:
     """Device-resident packed weights of one convolution (built once per layer)."""
 
-    def __init__(self, w_oihw, bias, c0: int, c1: int = 0, device="cuda", winograd: bool = True, split: bool = True):
+    def __init__(self, w_oihw, bias, c0: int, c1: int = 0, device="cuda", winograd: bool = True, split: bool = True, up: bool = True):
         import numpy as np
         w = np.asarray(w_oihw, dtype=np.float32)
         self.cout, cin, self.ksize, _ = w.shape
@@ -57,6 +57,12 @@ class PackedConv:
         if split:
             img, self.split_unscale = _abi.pack_conv_weights_split(w, c0, c1)
             self.w_split = torch.from_numpy(img).to(device)
+        # ... and, for 3x3 layers, the four phase images that turn "nearest-2x upsample, then 3x3" into four 2x2 convolutions on the
+        # low-resolution source (cdx.h wpacked_split_up; used only by launches with upsample=True)
+        self.w_split_up, self.split_up_unscale = None, None
+        if split and up and self.ksize == 3:
+            img, self.split_up_unscale = _abi.pack_conv_weights_split_up(w, c0, c1)
+            self.w_split_up = torch.from_numpy(img).to(device)
         self.bias = None if bias is None else torch.as_tensor(np.asarray(bias, np.float32)).to(device)
 
 
@@ -151,6 +157,10 @@ def conv_args(pc: PackedConv, src0, src1, out, *, stride=1, upsample=False, gn=N
     a.wpacked, a.bias = _ptr(pc.w), _ptr(pc.bias)
     a.wpacked_wino = _ptr(pc.w_wino)
     a.wpacked_split, a.wsplit_unscale = _ptr(pc.w_split), pc.split_unscale
+    if upsample and pc.w_split_up is not None:
+        a.wpacked_split_up = _ptr(pc.w_split_up)
+        for i, u in enumerate(pc.split_up_unscale):
+            a.wsplit_up_unscale[i] = u
     if gn is not None:
         a.gn_scale, a.gn_shift = _ptr(gn[0]), _ptr(gn[1])
         a.gn_exp = int(gn[2]) if len(gn) > 2 else 0

@@ -324,8 +324,9 @@ class UNet:
                 for b in res_blocks:    # up-path ResBlocks read (x, skip) as two sources
                     if b.skip_ch and base in (b.name + ".conv1", b.name + ".skip"):
                         c0, c1 = b.cin - b.skip_ch, b.skip_ch
+                is_up = any(b.kind == "up" and b.name == base for b in g.up)      # (only up-sampling layers need the phase images)
                 self.convs[base] = (ops.PackedConv16(w, bias, c0, c1, self.device, bf16=self.bf16) if self.half else
-                                    ops.PackedConv(w, bias, c0, c1, self.device, split=split))
+                                    ops.PackedConv(w, bias, c0, c1, self.device, split=split, up=is_up))
             elif ".norm" in name or name.startswith("temb."):
                 self.dev[name] = up(P[name])
                 if ".norm" in name:

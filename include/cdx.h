@@ -105,6 +105,11 @@ typedef struct cdx_conv_args {
                               of max |x| over image b of src0 -- the `amax_out` words of the launch that produced src0, or
                               cdx_amax_f32's output (64-byte aligned) */
     const uint32_t* src_amax1; /* the same for src1 (c1 > 0) */
+    const uint16_t* wpacked_split_up; /* NULL, or the cdx_conv_pack_weights_split_up_f16 image of the same 3x3 weights: lets the
+                              library run a CDX_CONV_UPSAMPLE2X layer (low-resolution rows >= 32 pixels, no residual) as FOUR
+                              2x2 convolutions on the low-resolution source, one per output phase -- 2.25x fewer multiply-adds
+                              than the 3x3 convolution on the upsampled tensor, the same sum up to the rounding of the merged taps */
+    float wsplit_up_unscale[4]; /* the packer's four `unscale` outputs */
     int32_t stats_slots;   /* with stats_out: the slot count the buffer was sized for = cdx_conv_stats_slots(a) asked with EVERY
                               other field final (the range fields above decide the tile, the tile the slots); a launch
                               whose tile writes a different count returns CDX_EINVAL instead of overrunning the buffer */
@@ -164,6 +169,12 @@ int cdx_conv_pack_weights_wino_f32(const float* w_oihw, int32_t c0, int32_t c1, 
  *   = plane(W'[n = 32*ntile + (lane&31)][c = chunk_base + 16*j + 8*(lane>>5) + k][ky][kx]),  + 16 KiB zero pad.
  * Non-finite weights are rejected (CDX_EINVAL). */
 size_t cdx_conv_split_packed_halves(int32_t c0, int32_t c1, int32_t cout, int32_t ksize);
+/* HOST: phase images of a 3x3 weight for CDX_CONV_UPSAMPLE2X layers: phase (dy, dx), taps (ty, tx) of a 2x2 kernel,
+ *   W2[2 dy + dx][n][c][ty][tx] = sum_{ky in K(dy,ty)} sum_{kx in K(dx,tx)} W[n][c][ky][kx],  K(0,0) = {0}, K(0,1) = {1,2}, K(1,0) = {0,1}, K(1,1) = {2}
+ * (float64 sums, rounded once), each packed like a ksize-2 split image ([ntile][chunk][tap = 2 ty + tx][j][plane][lane][k]) with its
+ * own power-of-two scale; unscale4[phase] = 2^-s.  The four images follow each other (cdx_conv_split_up_packed_halves / 4 halves each). */
+size_t cdx_conv_split_up_packed_halves(int32_t c0, int32_t c1, int32_t cout);
+int cdx_conv_pack_weights_split_up_f16(const float* w_oihw, int32_t c0, int32_t c1, int32_t cout, uint16_t* packed, float* unscale4);
 int cdx_conv_pack_weights_split_f16(const float* w_oihw, int32_t c0, int32_t c1, int32_t cout, int32_t ksize,
                                     uint16_t* packed, float* unscale);
 

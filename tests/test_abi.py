@@ -184,3 +184,49 @@ def test_store_hazard_isa_check():
     for f in users:
         n, bad = ic.check(ic.device_asm(os.path.join(ic.CSRC, f)))
         assert not bad and (n > 0 or f != "conv_wino.hip"), (f, n, bad)
+
+
+def test_upsample_phase_packer_matches_its_definition(lib):
+    """cdx_conv_pack_weights_split_up_f16: four 2x2 kernels with merged taps; (a) the definition reproduces
+    conv3x3(nearest2x(x)) in float64, (b) the packed hi + lo planes hold exactly those merged weights times 2^s."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(0)
+    cout, c0 = 40, 48
+    w = rng.standard_normal((cout, c0, 3, 3)).astype(np.float32)
+    K = {(0, 0): [0], (0, 1): [1, 2], (1, 0): [0, 1], (1, 1): [2]}
+    w2 = np.zeros((4, cout, c0, 2, 2))
+    for dy in range(2):
+        for dx in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    w2[2 * dy + dx, :, :, ty, tx] = sum(w[:, :, ky, kx].astype(np.float64) for ky in K[(dy, ty)] for kx in K[(dx, tx)])
+    # (a) the phase decomposition is the same convolution
+    x = torch.from_numpy(rng.standard_normal((2, c0, 7, 9)))
+    want = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), torch.from_numpy(w).double(), padding=1)
+    got = torch.zeros_like(want)
+    for dy in range(2):
+        for dx in range(2):
+            xp = F.pad(x, (1 - dx, dx, 1 - dy, dy))          # 2x2 taps starting (1 - dy, 1 - dx) up / left of the output pixel
+            got[:, :, dy::2, dx::2] = F.conv2d(xp, torch.from_numpy(w2[2 * dy + dx]))
+    assert (got - want).abs().max().item() < 1e-12
+    # (b) the packed image
+    img, un = cdx._abi.pack_conv_weights_split_up(w, c0, 0)
+    per = img.size // 4
+    ntiles, nch = (cout + 31) // 32, (c0 + 31) // 32
+    for ph in range(4):
+        body = img[ph * per: ph * per + ntiles * nch * 4 * 2048].astype(np.float64).reshape(ntiles, nch, 4, 2, 2, 64, 8)
+        scale = 1.0 / un[ph]
+        assert scale == 2.0 ** round(np.log2(scale)) and 2 ** 13 <= np.abs(w2[ph].astype(np.float32)).max() * scale < 2 ** 14
+        for nt in range(ntiles):
+            for ch in range(nch):
+                for tap in range(4):
+                    for j in range(2):
+                        v = body[nt, ch, tap, j, 0] + body[nt, ch, tap, j, 1]          # hi + lo  [lane, k]
+                        for lane in (0, 17, 33, 63):
+                            n, cbase = nt * 32 + (lane & 31), ch * 32 + 16 * j + 8 * (lane >> 5)
+                            for k in (0, 5, 7):
+                                c = cbase + k
+                                exp = float(np.float32(w2[ph, n, c, tap >> 1, tap & 1])) * scale if n < cout and c < c0 else 0.0
+                                assert abs(v[lane, k] - exp) <= 2.0 ** -10 * max(1.0, abs(exp)) * 2.0 ** -11, (ph, n, c, tap)
+        assert not img[ph * per + ntiles * nch * 4 * 2048: (ph + 1) * per].any()      # zero tail pad

@@ -64,6 +64,8 @@ CONV_CASES = [
     (1, 128, 320, 36, 40, 3, 1, False),    # 2 x 128 + 64, ragged
     (1, 64, 192, 32, 64, 1, 1, False),     # 1x1, 128 + 64
     (1, 64, 160, 40, 40, 3, 1, False),     # 128 + 32: 2 x 2 layout with one empty N-tile
+    (2, 64, 128, 32, 32, 3, 1, True),      # upsampled from 32 wide: four 2x2 phase convolutions on the low-resolution source (split tile)
+    (1, 96, 192, 36, 40, 3, 1, True),      # ... ragged low-resolution grid, 128 + 64 channels
 ]
 
 

@@ -62,6 +62,7 @@ SHAPES = [
     (2, 64, 96, 32, 32, 1, 1, False),      # 1x1
     (2, 96, 160, 8, 8, 1, 1, False),       # 1x1 chunk-parallel
     (2, 64, 64, 8, 8, 3, 1, True),         # nearest-2x upsample fused, 16 px out
+    (1, 64, 128, 36, 32, 3, 1, True),      # nearest-2x upsample as four 2x2 phase convolutions (low-resolution rows >= 32 px)
 ]
 
 
