@@ -56,7 +56,10 @@ def conv_variant(a) -> tuple:
     if isinstance(a, cdx._abi.ConvF16Args):
         return (a.ksize, a.stride, logtw, "f16_64x128" if a.stride == 2 else "f16_128x128")
     tile = cdx._abi.lib().cdx_conv_select_tile(ctypes.byref(a))
-    return (a.ksize, a.stride, logtw, cdx._abi.TILE_NAMES[tile])
+    name = cdx._abi.TILE_NAMES[tile]
+    if name.startswith("split") and (a.flags & cdx._abi.CONV_UPSAMPLE2X) and a.wpacked_split_up and a.ksize == 3 and a.win >= 32 and not a.residual:
+        name = "split_up4x(2x2)"      # four 2x2 phase launches on the low-resolution source (conv_split.hip): 4/9 of the 3x3 layer's MFMAs
+    return (a.ksize, a.stride, logtw, name)
 
 
 def conv_flops(a) -> float:
@@ -112,6 +115,10 @@ def kernel_model(variant) -> dict:
         return {"name": "conv_wino8_kernel<WinoCfg<2,0>> (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
                 "executed_per_algorithmic": 1.0 / 2.25, "peak": FP32_MFMA_PEAK_TFLOPS, "wino": True, "flops_per_mfma_cycle": 64.0,
                 "pmc_pattern": "conv_wino8_kernel"}
+    if tile.startswith("split_up"):
+        return {"name": "conv16_ws_kernel<Conv16Cfg<KS = 2, ..., SPLIT, WS>> x 4 phases (3x3 after nearest-2x upsampling as four 2x2 convolutions on the low-resolution source)",
+                "executed_per_algorithmic": 3.0 * 4.0 / 9.0, "peak": FP16_MFMA_PEAK_TFLOPS, "wino": False, "flops_per_mfma_cycle": 1024.0,
+                "pmc_pattern": "Conv16Cfg<2, 1, 5, 4, 2, 0, 1, 1, 0, 1>"}
     if tile.startswith("split"):
         # float32 product on the fp16 matrix pipe: hi*hi + lo*hi + hi*lo = 3 fp16 MFMA FLOPs per algorithmic FLOP
         return {"name": ("conv16_ws_kernel<Conv16Cfg<..., SPLIT, WS>> (f32 conv as 3 x v_mfma_f32_32x32x16_f16 on hi|lo split operands; 4 MFMA + 4 producer waves)"

@@ -72,12 +72,12 @@ int conv16_dispatch(int ks, int stride, int logtw, bool bf, const Conv16Params& 
     if (ks == 3 && stride == 1 && logtw == 5 && p.abl) {
         switch (p.abl) {
             case 1: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 1>>(p, stream);
-            case 2: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 2>>(p, stream);
-            case 3: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 3>>(p, stream);
             case 4: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 4>>(p, stream);
             case 7: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 7>>(p, stream);
             case 5: return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 0, 1, 0, 1>>(p, stream);      // wave-specialised: 4 MFMA + 4 producer waves
-            case 6: return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 2048, 0, 1, 0, 1>>(p, stream);   // ... with round 2's loader (timing only)
+            case 6: return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 2, 0, 1, 0, 1>>(p, stream);      // ... producers stage only the first chunk (the MFMA waves' bound)
+            case 3: return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 1, 0, 1, 0, 1>>(p, stream);      // ... no epilogue
+            case 2: return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 3, 0, 1, 0, 1>>(p, stream);      // ... neither
             default: return CDX_ENOTSUP;
         }
     }

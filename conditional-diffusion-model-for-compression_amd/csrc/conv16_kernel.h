@@ -400,11 +400,11 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             issue_loads(0);
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
-            if (p.nchunks > 1) issue_loads(1);
+            if (p.nchunks > 1 && !(C::ABL & 2)) issue_loads(1);
             __syncthreads();
             for (int chunk = 0; chunk < p.nchunks; ++chunk) {
                 H* nxt = lds_all + ((chunk + 1) & 1) * C::LDS_HALVES;
-                if (chunk + 1 < p.nchunks) {
+                if (chunk + 1 < p.nchunks && !(C::ABL & 2)) {
 #pragma unroll
                     for (int i = 0; i < NPASS; ++i) write_pass(nxt, i);
                     if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
