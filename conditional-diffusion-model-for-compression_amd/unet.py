@@ -66,7 +66,8 @@ class _Plan:
         # ONE arena, zeroed by the first launch of every forward: float32 bit patterns whose maximum is max |x| of that image,
         # written by the producing convolution's epilogue (amax_out) or by a cdx_amax_f32 pass for tensors no convolution produced.
         split = net.split and not half
-        self.amax_arena = self._hold(torch.zeros(4096 if split else 1, B, _abi.AMAX_WORDS, dtype=torch.int32, device=dev))
+        # (at most one row per convolution output + the x_t | cond buffer + one per attention output)
+        self.amax_arena = self._hold(torch.zeros(2 * len(net.convs) + 16 if split else 1, B, _abi.AMAX_WORDS, dtype=torch.int32, device=dev))
         amax_slot = {}           # data_ptr of a tensor -> its row of the arena
         need_amax = set()        # data_ptrs of conv outputs an un-normalised split launch reads
         produced = {}            # data_ptr of a conv output -> the args struct of the launch that writes it
