@@ -11,6 +11,7 @@ using namespace cdx;
 namespace cdx {
 bool conv_split_ok(const cdx_conv_args* a);                       // conv_split.hip
 bool conv_split_up_ok(const cdx_conv_args* a);
+void conv_split_tile_shape(const cdx_conv_args* a, int& tw, int& th);
 int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant = 0);
 int conv_split_slots_per_tile(const cdx_conv_args* a);
 int amax_launch(const float* x, int x_ld, int batch, int n, int channels, unsigned* out, hipStream_t stream);   // range.hip
@@ -213,6 +214,11 @@ namespace {
 int slots_of(const cdx_conv_args* a, const Tile& t) {
     // the four-phase form of an upsampled 3x3 layer tiles the LOW-resolution grid, once per phase
     if (t.wcfg == WCFG_SPLIT && conv_split_up_ok(a)) return 4 * ceil_div(a->win, 32) * ceil_div(a->hin, 4) * t.wm;
+    if (t.wcfg == WCFG_SPLIT) {
+        int tw, th;
+        conv_split_tile_shape(a, tw, th);
+        return ceil_div(a->wout, tw) * ceil_div(a->hout, th) * t.wm;
+    }
     const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : a->wout >= 8 ? 3 : 2;
     const int tw = 1 << logtw, th = t.bm / tw;
     return ceil_div(a->wout, tw) * ceil_div(a->hout, th) * t.wm;

@@ -50,8 +50,13 @@ bool f16_kpar(const cdx_conv_f16_args* a) {
            (a->cout % 4) == 0;
 }
 
+// 3x3 stride-1 layers at >= 32 pixels wide: the 8 x 16-pixel wave-specialised tile (180-pixel halo = 3 staging passes instead of
+// 204 = 4: conv_split.hip conv_split_tile_shape)
+bool f16_tile816(const cdx_conv_f16_args* a) { return a->ksize == 3 && a->stride == 1 && a->wout >= 32; }
+
 void tile_grid(const cdx_conv_f16_args* a, int& logtw, int& tx, int& ty) {
     logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : a->wout >= 8 ? 3 : 2;
+    if (f16_tile816(a)) logtw = 4;
     const int bm = 32 * f16_mt(a), tw = 1 << logtw, th = bm / tw;
     tx = ceil_div(a->wout, tw);
     ty = ceil_div(a->hout, th);
@@ -59,33 +64,33 @@ void tile_grid(const cdx_conv_f16_args* a, int& logtw, int& tx, int& ty) {
 }  // namespace
 
 namespace cdx {
-int conv16_dispatch_bf16(int ks, int stride, int logtw, const Conv16Params& p, hipStream_t stream);
+int conv16_dispatch_bf16(int ks, int stride, int logtw, int mt, const Conv16Params& p, hipStream_t stream);
 int conv16_kpar_dispatch_bf16(int ks, const Conv16Params& p, hipStream_t stream);
 int conv16_kpar_dispatch(int ks, bool bf, const Conv16Params& p, hipStream_t stream) {
     if (bf) return conv16_kpar_dispatch_bf16(ks, p, stream);
     if (ks == 3) return conv_kpar_launch<KparCfg<3, 3, 0, 0>>(p, stream);
     return conv_kpar_launch<KparCfg<1, 3, 0, 0>>(p, stream);
 }
-int conv16_dispatch(int ks, int stride, int logtw, bool bf, const Conv16Params& p, hipStream_t stream) {
+int conv16_dispatch(int ks, int stride, int logtw, int mt, bool bf, const Conv16Params& p, hipStream_t stream) {
 #ifdef CDX_TUNING
     // timing ablations of the dominant shape (libcdx_tune.so only), selected by flag bits 8..10
-    if (ks == 3 && stride == 1 && logtw == 5 && p.abl) {
+    if (ks == 3 && stride == 1 && logtw == 4 && mt == 4 && p.abl) {
         switch (p.abl) {
-            case 1: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 1>>(p, stream);
-            case 4: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 4>>(p, stream);
-            case 7: return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 7>>(p, stream);
-            case 5: return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 0, 1, 0, 1>>(p, stream);      // wave-specialised: 4 MFMA + 4 producer waves
-            case 6: return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 2, 0, 1, 0, 1>>(p, stream);      // ... producers stage only the first chunk (the MFMA waves' bound)
-            case 3: return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 1, 0, 1, 0, 1>>(p, stream);      // ... no epilogue
-            case 2: return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 3, 0, 1, 0, 1>>(p, stream);      // ... neither
+            case 1: return conv16_launch<Conv16Cfg<3, 1, 4, 4, 3, 1>>(p, stream);
+            case 4: return conv16_launch<Conv16Cfg<3, 1, 4, 4, 3, 4>>(p, stream);
+            case 7: return conv16_launch<Conv16Cfg<3, 1, 4, 4, 3, 7>>(p, stream);
+            case 5: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 0, 0, 1, 0, 1>>(p, stream);      // wave-specialised: 4 MFMA + 4 producer waves
+            case 6: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 2, 0, 1, 0, 1>>(p, stream);      // ... producers stage only the first chunk (the MFMA waves' bound)
+            case 3: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 1, 0, 1, 0, 1>>(p, stream);      // ... no epilogue
+            case 2: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 3, 0, 1, 0, 1>>(p, stream);      // ... neither
             default: return CDX_ENOTSUP;
         }
     }
 #endif
-    if (bf) return conv16_dispatch_bf16(ks, stride, logtw, p, stream);      // conv16_bf16.hip
+    if (bf) return conv16_dispatch_bf16(ks, stride, logtw, mt, p, stream);      // conv16_bf16.hip
     // 3x3 at >= 32 pixels wide: the wave-specialised workgroup (4 MFMA + 4 producer waves, conv16_kernel.h WS): with one MFMA per
     // (tap, 16 channels, M-tile) the staging arithmetic was 40 % of the 4-wave kernel -- +7...14 % in-process (profiles/r03_*)
-    if (ks == 3 && stride == 1 && logtw == 5) return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 0, 1, 0, 1>>(p, stream);
+    if (ks == 3 && stride == 1 && logtw == 4 && mt == 4) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 0, 0, 1, 0, 1>>(p, stream);
 #define C16(KS, ST, LT, MT) if (ks == KS && stride == ST && logtw == LT) return conv16_launch<Conv16Cfg<KS, ST, LT, MT>>(p, stream);
     C16(3, 1, 2, 4) C16(3, 1, 3, 2) C16(3, 1, 4, 2)
     C16(1, 1, 2, 4) C16(1, 1, 3, 2) C16(1, 1, 4, 2) C16(1, 1, 5, 4)
@@ -188,6 +193,6 @@ extern "C" int cdx_conv_f16(const cdx_conv_f16_args* a, void*, size_t, cdx_strea
     tile_grid(a, logtw, p.tiles_x, p.tiles_y);
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
     if (f16_kpar(a)) return conv16_kpar_dispatch(a->ksize, (a->flags & CDX_CONV_BF16) != 0, p, static_cast<hipStream_t>(stream));
-    return conv16_dispatch(a->ksize, a->stride, logtw, (a->flags & CDX_CONV_BF16) != 0, p, static_cast<hipStream_t>(stream));
+    return conv16_dispatch(a->ksize, a->stride, logtw, f16_mt(a), (a->flags & CDX_CONV_BF16) != 0, p, static_cast<hipStream_t>(stream));
 }
 

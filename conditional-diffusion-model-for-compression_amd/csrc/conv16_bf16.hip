@@ -4,8 +4,8 @@
 #include "conv_kpar_kernel.h"
 
 namespace cdx {
-int conv16_dispatch_bf16(int ks, int stride, int logtw, const Conv16Params& p, hipStream_t stream) {
-    if (ks == 3 && stride == 1 && logtw == 5) return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 0, 1, 1, 1>>(p, stream);      // wave-specialised (conv16.hip)
+int conv16_dispatch_bf16(int ks, int stride, int logtw, int mt, const Conv16Params& p, hipStream_t stream) {
+    if (ks == 3 && stride == 1 && logtw == 4 && mt == 4) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 0, 0, 1, 1, 1>>(p, stream);      // wave-specialised 8 x 16 tile (conv16.hip)
 #define C16(KS, ST, LT, MT) if (ks == KS && stride == ST && logtw == LT) return conv16_launch<Conv16Cfg<KS, ST, LT, MT, 3, 0, 0, 1, 1>>(p, stream);
     C16(3, 1, 2, 4) C16(3, 1, 3, 2) C16(3, 1, 4, 2)
     C16(1, 1, 2, 4) C16(1, 1, 3, 2) C16(1, 1, 4, 2) C16(1, 1, 5, 4)

@@ -922,6 +922,6 @@ inline int conv16_launch(const Conv16Params& p, hipStream_t stream) {
     return check_launch();
 }
 
-int conv16_dispatch(int ks, int stride, int logtw, bool bf, const Conv16Params& p, hipStream_t stream);
+int conv16_dispatch(int ks, int stride, int logtw, int mt, bool bf, const Conv16Params& p, hipStream_t stream);
 
 }  // namespace cdx

@@ -145,6 +145,17 @@ bool conv_split_up_ok(const cdx_conv_args* a) {
            a->wsplit_up_unscale[3] > 0.f;
 }
 
+// Spatial tiling of a SPLIT launch (also asked by cdx_conv_stats_slots).  3x3 stride-1 layers at >= 32 pixels wide use an 8 x 16-pixel
+// tile: its 10 x 18 halo is 180 pixels = 3 staging passes of 64, where the 4 x 32 tile's 6 x 34 halo is 204 pixels = 4 passes with 52
+// empty slots -- a quarter less staging work for the producer waves and 12 % fewer halo bytes, bit-identical results (+1.2...2 %
+// in-process, tools/conv_bench.py --tiles 11,109 before the switch).  1x1 layers (no halo) and the phase launches keep 4 x 32.
+void conv_split_tile_shape(const cdx_conv_args* a, int& tw, int& th) {
+    if (a->stride == 2) { tw = a->wout >= 32 ? 32 : 16; th = 64 / tw; return; }
+    if (a->wout >= 32) { if (a->ksize == 3) { tw = 16; th = 8; } else { tw = 32; th = 4; } return; }
+    if (a->wout >= 16) { tw = 16; th = 4; return; }
+    tw = 8; th = 8;
+}
+
 // GroupNorm-sum slots per spatial tile of a SPLIT launch: 2 when the 128-pixel tile's last channel block runs 2 x 2
 int conv_split_slots_per_tile(const cdx_conv_args* a) {
     if (a->stride == 1 && a->wout < 16) return 4;      // chunk-parallel tile (conv_kpar_kernel.h): one slot per finishing wave
@@ -201,8 +212,9 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
         }
         return CDX_OK;
     }
-    const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : 3, tw = 1 << logtw;
-    const int bm = (a->stride == 2 || a->wout < 32) ? 64 : 128, th = bm / tw;
+    const int logtw = a->wout >= 32 ? 5 : a->wout >= 16 ? 4 : 3;
+    int tw, th;
+    conv_split_tile_shape(a, tw, th);
     p.tiles_x = ceil_div(a->wout, tw);
     p.tiles_y = ceil_div(a->hout, th);
     CDX_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.B < (1ll << 31));
@@ -220,6 +232,10 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
         return conv_kpar_launch<KparCfg<1, 3>>(p, stream);
     }
 #ifdef CDX_TUNING
+    if (a->ksize == 3 && variant) {      // the tuning variants are 4 x 32-pixel tiles (round 2's geometry)
+        p.tiles_x = ceil_div(a->wout, 32);
+        p.tiles_y = ceil_div(a->hout, 4);
+    }
     if (a->ksize == 1 && variant == 40) return conv16_ws_launch<Conv16Cfg<1, 1, 5, 4, 3, 0, 1, 1, 0, 1>>(p, stream);
     if (a->ksize == 3 && variant == 46) return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 1>>(p, stream);      // the 4-wave tile (round 2's product)
     if (a->ksize == 3 && variant) {      // timing ablations / tuning variants (tools/conv_bench.py --tiles 60..)
@@ -261,7 +277,7 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     // 3x3 at >= 32 pixels wide (79 % of the cfg2 step): the WAVE-SPECIALISED workgroup -- 4 MFMA waves + 4 producer waves
     // (conv16_kernel.h WS): bit-identical to the 4-wave tile, +3...5 % (in-process A/B, profiles/r03_*); the HBM-bound 1x1
     // layers gain nothing from it and keep the 4-wave form
-    if (a->ksize == 3) return conv16_ws_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 1, 1, 0, 1>>(p, stream);
+    if (a->ksize == 3) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 0, 1, 1, 0, 1>>(p, stream);      // 8 x 16-pixel tile (conv_split_tile_shape)
     return conv16_launch<Conv16Cfg<1, 1, 5, 4, 3, 0, 1>>(p, stream);
 }
 }  // namespace cdx
