@@ -453,9 +453,13 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             // rows past the image end / columns past the row end read other (or no: bounded resource) pixels; those
             // accumulators are never stored
             constexpr unsigned es = C::SPLIT ? 4u : 2u;
+            // (a wave of the 2 x 2 layout may own tile rows that lie wholly past the image -- H = 2 with 4-row tiles: `first` is then at
+            // or beyond the tensor's end and the resource must be EMPTY, not wrap to 4 GiB of whatever follows the tensor: found by
+            // the 800-case fuzz of round 3 as a GPU memory fault; the unmasked loads below rely on the bound)
             const size_t first = (((size_t)b * p.Hout + oy0w) * p.Wout + ox0) * p.Cout;
-            const size_t left = ((size_t)p.B * p.Hout * p.Wout * p.Cout - first) * es;
-            const __amdgpu_buffer_rsrc_t rr = buf_rsrc(static_cast<const char*>(p.residual) + first * es,
+            const size_t total = (size_t)p.B * p.Hout * p.Wout * p.Cout;
+            const size_t left = first < total ? (total - first) * es : 1;          // (1 byte: every 2- / 4-byte access is out of range, whatever a zero size means)
+            const __amdgpu_buffer_rsrc_t rr = buf_rsrc(static_cast<const char*>(p.residual) + (first < total ? first : 0) * es,
                                                        left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)left);
             const unsigned voff = ((unsigned)(4 * lh) * (unsigned)p.Cout + (unsigned)n) * es;
 #pragma unroll
@@ -615,9 +619,10 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         // (phase launches: output pixel (y, x) lands at (os y + ody, os x + odx) of the os-times larger tensor; os = 1 otherwise)
         const unsigned os = (unsigned)p.ostep, WoutF = (unsigned)p.Wout * os;
         const size_t first = (((size_t)b * p.Hout * os + (size_t)oy0w * os + p.ody) * WoutF + (size_t)ox0 * os + p.odx) * p.out_ld;
-        const size_t left = ((size_t)p.B * p.Hout * os * WoutF * p.out_ld - first) * 4;
+        const size_t total = (size_t)p.B * p.Hout * os * WoutF * p.out_ld;
+        const size_t left = first < total ? (total - first) * 4 : 1;              // (tile rows wholly past the image: a resource no dword fits into)
         constexpr unsigned kDrop = 0x80000000u;                                    // beyond any resource: the store is dropped
-        const __amdgpu_buffer_rsrc_t ors = buf_rsrc(static_cast<float*>(p.out) + first, left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)left);
+        const __amdgpu_buffer_rsrc_t ors = buf_rsrc(static_cast<float*>(p.out) + (first < total ? first : 0), left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)left);
         const unsigned vbase = nok ? ((unsigned)(4 * lh) * os * (unsigned)p.out_ld + (unsigned)n) * 4u : kDrop;
         float un = asc.un;
         if (asc.late) {                              // (rare: see ActScale) outputs first, then the additive terms at their own scale
@@ -687,9 +692,10 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             constexpr int ROWS = (MT * 32) >> C::LOGTW;
             const bool full = oy0w + ROWS <= p.Hout && ox0 + C::TW <= p.Wout;      // wave-uniform
             const size_t first = (((size_t)b * p.Hout + oy0w) * p.Wout + ox0) * p.out_ld;
-            const size_t left = ((size_t)p.B * p.Hout * p.Wout * p.out_ld - first) * 2;
+            const size_t total = (size_t)p.B * p.Hout * p.Wout * p.out_ld;
+            const size_t left = first < total ? (total - first) * 2 : 1;          // (tile rows wholly past the image: a resource no dword fits into)
             constexpr unsigned kDrop = 0x80000000u;
-            const __amdgpu_buffer_rsrc_t ors = buf_rsrc(static_cast<H*>(p.out) + first, left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)left);
+            const __amdgpu_buffer_rsrc_t ors = buf_rsrc(static_cast<H*>(p.out) + (first < total ? first : 0), left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)left);
             const int odd = li & 1;
             const unsigned vbase = nok ? ((unsigned)(4 * lh + odd) * (unsigned)p.out_ld + (unsigned)(n - odd)) * 2u : kDrop;
             const unsigned rot = odd ? 16u : 0u;

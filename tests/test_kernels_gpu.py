@@ -211,6 +211,35 @@ def test_split_tiles_repeatable_across_launch_sequences(cdx_mod):
                 assert torch.equal(got, first[key]), f"round {rnd_i} case {j}: result changed between launches"
 
 
+@pytest.mark.parametrize("k,H,W,ci,c1,co", [(1, 2, 68, 64, 32, 160), (3, 2, 68, 64, 0, 160), (3, 5, 40, 32, 0, 192), (1, 3, 33, 64, 0, 96)])
+@pytest.mark.parametrize("half", [False, True], ids=["f32", "fp16"])
+def test_tile_rows_past_the_image_with_residual(cdx_mod, k, H, W, ci, c1, co, half):
+    """Found by the 800-case fuzz of round 3 (GPU memory fault): an image 2 rows high under 4-row tiles, cout = 128 + 32 -- the waves of
+    the 2 x 2 tail layout that own rows 2..3 built their residual resource from an offset PAST the tensor.  Must compute and not fault."""
+    ops = cdx_mod.ops
+    x0, x1 = rnd(1, ci, H, W, seed=70), (rnd(1, c1, H, W, seed=71) if c1 else None)
+    w = rnd(co, ci + c1, k, k, seed=72, scale=1.0 / math.sqrt((ci + c1) * k * k))
+    bias, res = rnd(co, seed=73), rnd(1, co, H, W, seed=74)
+    gamma, beta = 1 + 0.2 * rnd(ci + c1, seed=75), 0.3 * rnd(ci + c1, seed=76)
+    xc = torch.cat([x0, x1], 1) if c1 else x0
+    if half:
+        xc, res = xc.half().float(), res.half().float()
+        pc = ops.PackedConv16(w.numpy(), bias.numpy(), ci, c1)
+        s0, s1 = nhwc(xc[:, :ci]).half(), (nhwc(xc[:, ci:]).half() if c1 else None)
+        sc, sh = ops.gn_stats(s0.float(), None if s1 is None else s1.float(), gamma.cuda(), beta.cuda(), 32)
+        got, st = ops.conv16(pc, s0, s1, gn=(sc, sh), silu=True, residual=nhwc(res).half(), want_stats=True)
+        got = nchw(got.float())
+        want = F.conv2d(F.silu(F.group_norm(xc.double(), 32, gamma.double(), beta.double())).float().half().double(), w.half().double(), bias.double(), padding=k // 2) + res.double()
+        close(got, want, 3e-3, "fp16 conv, tile rows past the image")
+    else:
+        pc = ops.PackedConv(w.numpy(), bias.numpy(), ci, c1)
+        got, st = ops.conv(pc, nhwc(xc[:, :ci]), nhwc(xc[:, ci:]) if c1 else None, gn_affine=(gamma.cuda(), beta.cuda(), 32), silu=True,
+                           residual=nhwc(res), want_stats=True)
+        want = F.conv2d(F.silu(F.group_norm(xc.double(), 32, gamma.double(), beta.double())), w.double(), bias.double(), padding=k // 2) + res.double()
+        close(nchw(got), want, 3e-6, "conv, tile rows past the image")
+    assert not torch.isnan(st).any()
+
+
 def test_gn_no_silu_1x1(cdx_mod):
     """Attention's qkv projection: conv1x1(gn(x)), no activation."""
     ops = cdx_mod.ops

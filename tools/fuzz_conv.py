@@ -15,6 +15,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
 nchw = lambda t: t.permute(0, 3, 1, 2).contiguous().cpu()
 bad, tiles_seen = 0, {}
+_trace = open(os.environ['FUZZ_TRACE'], 'a') if os.environ.get('FUZZ_TRACE') else None      # per-case log, flushed BEFORE the launch
 for case in range(ncases):
     k = int(rng.choice([3, 3, 3, 1]))
     s = int(rng.choice([1, 1, 1, 2])) if k == 3 else 1
@@ -62,6 +63,8 @@ for case in range(ncases):
     if use_temb: kw.update(temb=temb.float().cuda(), temb_off=1)
     if use_res: kw["residual"] = nhwc(res.float())
     pc = ops.PackedConv(w.float().numpy(), bias.float().numpy(), c0, c1, split=(case % 3 != 0))      # every third case: f32-MFMA kernels only
+    if _trace:
+        _trace.write(f"case {case} " + repr(dict(B=B, c0=c0, c1=c1, co=co, H=H, W=W, k=k, s=s, up=up, gn=gn, silu=silu, temb=use_temb, res=use_res, stats=want_stats, split=(case % 3 != 0))) + "\n"); _trace.flush(); torch.cuda.synchronize()
     try:
         out = torch.full((B, ho, wo, co), float("nan"), device="cuda")
         if want_stats:

@@ -13,6 +13,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
 nchw = lambda t: t.permute(0, 3, 1, 2).contiguous().cpu()
 bad = 0
+_trace = open(os.environ['FUZZ_TRACE'], 'a') if os.environ.get('FUZZ_TRACE') else None      # per-case log, flushed BEFORE the launch
 for case in range(ncases):
     k = int(rng.choice([3, 3, 3, 1]))
     s = int(rng.choice([1, 1, 1, 2])) if k == 3 else 1
@@ -60,6 +61,8 @@ for case in range(ncases):
     if use_temb: kw.update(temb=temb.cuda(), temb_off=1)
     if res is not None: kw["residual"] = nhwc(res)
     pc = ops.PackedConv16(w.float().numpy(), bias.numpy(), c0, c1)
+    if _trace:
+        _trace.write(f"case {case} " + repr(dict(B=B, c0=c0, c1=c1, co=co, H=H, W=W, k=k, s=s, up=up, gn=gn, silu=silu, temb=use_temb, res=res is not None, out32=out32, stats=want_stats)) + "\n"); _trace.flush(); torch.cuda.synchronize()
     try:
         r = ops.conv16(pc, s0, s1, out_dtype=torch.float32 if out32 else torch.float16, want_stats=want_stats, **kw)
         out = r[0] if want_stats else r
