@@ -155,7 +155,7 @@ OPS = {
 
 # every exported symbol include/cdx.h declares (checked by tests/test_abi.py without a GPU)
 TILE_SPLIT = 11
-TILE_NAMES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "64x128", 4: "64x64", 5: "S32x32", 6: "S64x32", 7: "wino128x128", 8: "small256x4", 9: "small256x4valu", 10: "cin8_128x128", 11: "split128x128"}
+TILE_NAMES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "64x128", 4: "64x64", 5: "S32x32", 6: "S64x32", 7: "wino128x128", 8: "small256x4", 9: "small256x4valu", 10: "cin8_128x128", 11: "split128x128", 12: "smallgemm512x3"}
 
 EXPORTS = (["cdx_abi_version", "cdx_strerror", "cdx_launch_count",
             "cdx_conv_packed_floats", "cdx_conv_pack_weights_f32", "cdx_conv_select_tile", "cdx_conv_f32_tile",

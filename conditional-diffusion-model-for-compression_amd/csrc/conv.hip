@@ -110,6 +110,7 @@ Tile tile_of(int wcfg) {
         case WCFG_CIN8: return {wcfg, 128, 128, 1};    // 128x128 tile that multiplies only the first 8 channels of the chunk
         case WCFG_SMALL: return {wcfg, 256, 4, 1};     // 8 x 32 pixels, cout <= 4 (4x4x1 MFMA form)
         case WCFG_SMALL_VALU: return {wcfg, 256, 4, 1};   // same tile, vector-ALU form (scalar-cache weights)
+        case WCFG_SMALL_GEMM: return {wcfg, 512, 4, 1};   // 16 x 32 pixels, cout <= 3, taps as GEMM columns (v_mfma_f32_32x32x2_f32)
         case WCFG_SPLIT: return {wcfg, 128, 128, 1};      // fp16 matrix pipe, operands split hi/lo (conv16_kernel.h SPLIT)
         default: return {-1, 0, 0, 0};
     }
@@ -123,6 +124,11 @@ bool wino_ok(const cdx_conv_args* a) {
 // cout <= 4 (conv_out): the vector-ALU kernel of conv_small.hip (no GroupNorm sums of the output: nothing normalises it)
 bool small_ok(const cdx_conv_args* a) {
     return a->ksize == 3 && a->stride == 1 && a->cout <= 4 && a->wout >= 32 && a->stats_out == nullptr;
+}
+
+// ... and, for one source of 64 / 128 / 192 / 256 channels and cout <= 3, the GEMM form over (tap, cout) columns (HBM-bound)
+bool small_gemm_ok(const cdx_conv_args* a) {
+    return small_ok(a) && a->cout <= 3 && a->c1 == 0 && !(a->flags & CDX_CONV_UPSAMPLE2X) && a->c0 >= 64 && a->c0 <= 256 && a->c0 % 64 == 0;
 }
 
 // at most 8 input channels in ONE source (conv_in: x_t | cond | pad): the direct kernel without the 24 zero channels of its
@@ -156,6 +162,7 @@ Tile select_tile(const cdx_conv_args* a) {
         if (hw <= kSplitKMaxPixels) t = tile_of(a->stride == 1 && hw >= 256 ? WCFG_S64 : WCFG_S32);
         else if (cin8_ok(a)) t = tile_of(WCFG_CIN8);
         else if (wino_ok(a) && a->cout >= 96) t = tile_of(WCFG_WINO);
+        else if (small_gemm_ok(a)) t = tile_of(WCFG_SMALL_GEMM);
         else if (small_ok(a)) t = tile_of(WCFG_SMALL);
     }
     return t;
@@ -168,6 +175,7 @@ bool tile_allowed(const cdx_conv_args* a, int wcfg) {
     if (wcfg == WCFG_WINO) return wino_ok(a);
     if (wcfg == WCFG_CIN8) return cin8_ok(a);
     if (wcfg == WCFG_SMALL || wcfg == WCFG_SMALL_VALU) return small_ok(a);
+    if (wcfg == WCFG_SMALL_GEMM) return small_gemm_ok(a);
     return wcfg == WCFG_1x4x4 || wcfg == WCFG_2x2x2 || wcfg == WCFG_4x1x1 || wcfg == WCFG_S32 || wcfg == WCFG_S64;
 }
 
@@ -293,6 +301,7 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
         p.w = a->wpacked_wino;
         rc = conv_dispatch_wino(experimental ? tile : 0, p, st);
     } else if (t.wcfg == WCFG_SMALL || t.wcfg == WCFG_SMALL_VALU) rc = conv_dispatch_small(p, st, t.wcfg == WCFG_SMALL_VALU);
+    else if (t.wcfg == WCFG_SMALL_GEMM) rc = conv_dispatch_small_gemm(p, st);
 #ifdef CDX_TUNING
     else if (experimental) rc = conv_dispatch_exp(logtw, t.wcfg, p, st);
 #endif

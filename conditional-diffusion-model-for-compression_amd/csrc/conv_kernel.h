@@ -390,8 +390,9 @@ inline int conv_launch(const ConvParams& p, hipStream_t stream) {
 // tile-shape ids used by the dispatcher (WM x WN x MT [x WK]); the S* shapes split K over the 4 waves
 // and exist for the low-resolution levels, where the big tiles would leave most CUs idle.
 enum { WCFG_1x4x4 = 0, WCFG_2x2x2 = 1, WCFG_4x1x1 = 2, WCFG_1x4x2 = 3, WCFG_2x2x1 = 4, WCFG_S32 = 5, WCFG_S64 = 6,
-       WCFG_WINO = 7, WCFG_SMALL = 8, WCFG_SMALL_VALU = 9, WCFG_CIN8 = 10, WCFG_SPLIT = 11 };
+       WCFG_WINO = 7, WCFG_SMALL = 8, WCFG_SMALL_VALU = 9, WCFG_CIN8 = 10, WCFG_SPLIT = 11, WCFG_SMALL_GEMM = 12 };
 int conv_dispatch_small(const ConvParams& p, hipStream_t stream, bool valu_form);   // conv_small.hip: 3x3 stride 1, cout <= 4
+int conv_dispatch_small_gemm(const ConvParams& p, hipStream_t stream);                // conv_small.hip: ... cout <= 3 as one GEMM over (tap, cout) columns
 
 int conv_dispatch_k3s1(int logtw, int wcfg, const ConvParams& p, hipStream_t stream);
 int conv_dispatch_k1s1(int logtw, int wcfg, const ConvParams& p, hipStream_t stream);

@@ -6,6 +6,7 @@
 // 64 bytes at lane 0 hold W[n = 0..3][channels 8s .. 8s+3] and the 64 bytes at lane 32 the channels 8s+4 .. 8s+7.
 // Every FMA takes its weight as an SGPR operand: 9 x Cin x NCO FMAs and 9 x Cin / 4 ds_read_b128 per pixel.
 // Bound: VALU (3456 FMA issues per wave at 128 -> 3), ~0.1 ms at configs[1].  No reference file exists to cite.
+#include <cstdlib>
 #include "conv_kernel.h"
 
 namespace cdx {
@@ -250,7 +251,191 @@ __global__ __launch_bounds__(256, 2) void conv_small_mfma_kernel(const ConvParam
     }
 }
 
+// GEMM form (CDX_TILE_SMALL_GEMM): the two kernels above give every output pixel its own pass over the 9 x Cin LDS
+// neighbourhood -- 216 ds_read_b128 per wave and 32-channel chunk, which is what bounds them (the LDS pipe: 0.24 ms at
+// configs[1] where the tensor streams in 0.11).  Here the taps become OUTPUT columns: Y[p][tap*3 + co] = sum_c X[p][c] W[co][c][tap]
+// is ONE plain GEMM over the pixels of the 18 x 34 halo (N = 27 of the 32 columns of v_mfma_f32_32x32x2_f32, K = Cin), whose A
+// operand goes from global memory through GroupNorm + SiLU straight into the MFMA -- no activation ever touches LDS -- and
+// out[p][co] = sum_tap Y[p + tap offset][tap*3 + co] gathers 27 words per pixel from the 66 KB LDS image of Y.  Lane (m, half) of a
+// 32-pixel block owns channels 32 J + 16 half + 4 i + e (4 back-to-back 16-byte loads = its 64-byte half of a 128-byte line);
+// the matching weight fragments sit in registers (16 per 32 channels: one float4 each, straight out of the MFMA-packed image
+// of output tile 0; above 128 channels in two passes over the tile, each with half of them, the second adding into Y).  20 blocks per 16 x 32-pixel tile (1.25 x the pixels), 5 per wave.  Bound: HBM (the input, once).
+constexpr int G_TW = 32, G_TH = 16, G_HW = G_TW + 2, G_HH = G_TH + 2, G_NPIX = G_HH * G_HW, G_NBLK = (G_NPIX + 31) / 32, G_NV = 27;
+static_assert(G_NBLK % 4 == 0, "blocks are dealt to 4 waves");
+
+template <int NJ4, int KSPL, bool SILU, int ABL = 0>      // NJ4 = Cin / 32; KSPL passes over the tile, each with 1 / KSPL of the channels' weights in registers
+__global__ __launch_bounds__(256, 2) void conv_small_gemm_kernel(const ConvParams p) {
+    __shared__ float yl[G_NPIX * G_NV];
+    __shared__ __attribute__((aligned(16))) float ssl[2][NJ4 * 32];
+    constexpr int NJH = NJ4 / KSPL;
+    static_assert(NJH * KSPL == NJ4 && NJH <= 4, "NJH x 16 weight registers per lane");
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, m = lane & 31, half = lane >> 5;
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int b = bx / p.tiles_y;
+    const int oy0 = ty * G_TH, ox0 = tx * G_TW;
+    const int cin = NJ4 * 32;
+
+    for (int c = tid; c < cin; c += 256) {
+        ssl[0][c] = p.gn ? p.gscale[(size_t)b * p.ctot + c] : 1.f;
+        ssl[1][c] = p.gn ? p.gshift[(size_t)b * p.ctot + c] : 0.f;
+    }
+    __syncthreads();
+
+    const int tap = m / 3, co = m - 3 * tap;
+    const bool wok = m < G_NV && co < p.Cout;
+    const float* __restrict__ img = p.src[0] + (size_t)b * p.Hin * p.Win * cin + 16 * half;
+    // this lane's pixel of block (pass ks, round k): its address (padding lanes: a safe one, zeroed after the arithmetic) and validity
+    auto pixel_of = [&](int ks, int k, bool& inimg) -> const float* {
+        const int blk = wv + 4 * k;
+        const int hp = (ABL & 2) ? wv * 32 + m : blk * 32 + m;      // (ABL 2: every block re-reads block wv's pixels -- cache hits)
+        const int hy = hp / G_HW, hx = hp - hy * G_HW;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        inimg = hp < G_NPIX && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        return img + (inimg ? ((size_t)iy * p.Win + ix) * cin : 0) + ks * NJH * 32;
+    };
+    // the loads run ONE WHOLE BLOCK ahead of the arithmetic (NJH x 64 bytes per lane in flight): x[J] is refilled for the next block
+    // as soon as step J of this one has read it -- with the loads of a block issued at its start the kernel took memory time
+    // PLUS matrix time (0.118 + 0.132 of 0.227 ms at configs[1], tools/session/gpu_r3ac.sh)
+    f32x4 x[NJH][4];
+    bool in_cur;
+    const float* __restrict__ px = pixel_of(0, 0, in_cur);
+#pragma unroll
+    for (int J = 0; J < NJH; ++J)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[J][i] = *reinterpret_cast<const f32x4*>(px + 32 * J + 4 * i);
+#pragma unroll 1
+    for (int ks = 0; ks < KSPL; ++ks) {
+        // B fragments: lane (n = tap*3 + co, half) holds W[co][32 J + 16 half + 4 i + e][tap] = the float4 at (chunk J, tap,
+        // s = 2 half + i/2, lane (i & 1) * 32 + co) of the packed image; columns 27..31 and absent output channels multiply zeros
+        f32x4 wreg[NJH][4];
+#pragma unroll
+        for (int J = 0; J < NJH; ++J)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                wreg[J][i] = wok ? *reinterpret_cast<const f32x4*>(p.w + (size_t)(ks * NJH + J) * (9 * 1024) + (tap * 4 + 2 * half + (i >> 1)) * 256 + (i & 1) * 128 + co * 4)
+                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* __restrict__ ssc = &ssl[0][ks * NJH * 32 + 16 * half];
+        const float* __restrict__ ssh = &ssl[1][ks * NJH * 32 + 16 * half];
+#pragma unroll 1
+        for (int k = 0; k < G_NBLK / 4; ++k) {
+            const int blk = wv + 4 * k;
+            const bool inimg = in_cur;
+            const bool last_k = k + 1 == G_NBLK / 4;
+            const bool more = !(last_k && ks + 1 == KSPL);                      // wave-uniform
+            bool in_next = false;
+            const float* __restrict__ pn = more ? pixel_of(last_k ? ks + 1 : ks, last_k ? 0 : k + 1, in_next) : px;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            int fresh = 0;                                   // (opaque: scale / shift are re-read from LDS per block -- hoisted out of
+            asm volatile("" : "+v"(fresh));                  //  the loop they would pin 32 registers per 32 channels)
+#pragma unroll
+            for (int J = 0; J < NJH; ++J) {
+                f32x4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(ssc + fresh + 32 * J + 4 * i);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(ssh + fresh + 32 * J + 4 * i);
+                    v[i] = x[J][i];
+                    if constexpr (!(ABL & 4)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[i][e] = fmaf(v[i][e], sc[e], sh[e]);
+                            if constexpr (SILU) v[i][e] = silu_f<false>(v[i][e]);
+                            v[i][e] = inimg ? v[i][e] : 0.f;        // zero padding of the ACTIVATED tensor (and NaN-free dummy reads)
+                        }
+                    }
+                }
+                if (more) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x[J][i] = *reinterpret_cast<const f32x4*>(pn + 32 * J + 4 * i);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (ABL & 1) acc[e] = fmaf(v[i][e], wreg[J][i][e], acc[e]);      // (ABL 1: no MFMA)
+                        else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i][e], wreg[J][i][e], acc, 0, 0, 0);
+                    }
+            }
+            in_cur = in_next;
+            // lane (n, half), register r -> Y[pixel 32 blk + 8 (r / 4) + 4 half + (r & 3)][n]; later passes add (same lane, same word)
+            if (m < G_NV) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int hpr = blk * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                    if (hpr < G_NPIX) yl[hpr * G_NV + m] = ks ? yl[hpr * G_NV + m] + acc[r] : acc[r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = tid + 256 * i;
+        const int oyl = q >> 5, oxl = q & 31;
+        float sum[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* __restrict__ y = &yl[((oyl + tap / 3) * G_HW + oxl + tap % 3) * G_NV + tap * 3];
+#pragma unroll
+            for (int co = 0; co < 3; ++co) sum[co] += y[co];
+        }
+        const int oy = oy0 + oyl, ox = ox0 + oxl;
+        if (oy < p.Hout && ox < p.Wout) {
+            const size_t pix = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                if (co < p.Cout) {
+                    float v = sum[co];
+                    if (p.bias) v += p.bias[co];
+                    if (p.temb) v += p.temb[(size_t)b * p.temb_ld + co];
+                    if (p.residual) v += p.residual[pix * p.Cout + co];
+                    p.out[pix * p.out_ld + co] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int NJ4, int KSPL>
+int gemm_launch(const ConvParams& p, hipStream_t stream) {
+    dim3 grid(p.tiles_x * p.tiles_y * p.B, 1);
+#ifdef CDX_TUNING
+    if (const char* e = getenv("CDX_GEMM_ABL")) {      // timing ablations (WRONG RESULTS): 1 no MFMA, 2 cached input, 4 no GroupNorm / SiLU arithmetic
+        switch (atoi(e)) {
+            case 1: hipLaunchKernelGGL((conv_small_gemm_kernel<NJ4, KSPL, true, 1>), grid, dim3(256), 0, stream, p); return check_launch();
+            case 2: hipLaunchKernelGGL((conv_small_gemm_kernel<NJ4, KSPL, true, 2>), grid, dim3(256), 0, stream, p); return check_launch();
+            case 4: hipLaunchKernelGGL((conv_small_gemm_kernel<NJ4, KSPL, true, 4>), grid, dim3(256), 0, stream, p); return check_launch();
+            case 6: hipLaunchKernelGGL((conv_small_gemm_kernel<NJ4, KSPL, true, 6>), grid, dim3(256), 0, stream, p); return check_launch();
+            case 7: hipLaunchKernelGGL((conv_small_gemm_kernel<NJ4, KSPL, true, 7>), grid, dim3(256), 0, stream, p); return check_launch();
+            case 5: hipLaunchKernelGGL((conv_small_gemm_kernel<NJ4, KSPL, true, 5>), grid, dim3(256), 0, stream, p); return check_launch();
+            default: break;
+        }
+    }
+#endif
+    if (p.silu) hipLaunchKernelGGL((conv_small_gemm_kernel<NJ4, KSPL, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_small_gemm_kernel<NJ4, KSPL, false>), grid, dim3(256), 0, stream, p);
+    return check_launch();
+}
+
 }  // namespace
+
+// (conv.hip small_gemm_ok: one source of 64 / 128 / 192 / 256 channels, no upsampling, cout <= 3; 16 x 32-pixel tiles)
+int conv_dispatch_small_gemm(const ConvParams& p, hipStream_t stream) {
+    if (p.ups || p.nchunks != p.nchunk0 || p.Cout > 3 || p.Hin != p.Hout || p.Win != p.Wout) return CDX_ENOTSUP;
+    switch (p.csrc[0]) {
+        case 64: return gemm_launch<2, 1>(p, stream);
+        case 128: return gemm_launch<4, 1>(p, stream);
+        case 192: return gemm_launch<6, 2>(p, stream);
+        case 256: return gemm_launch<8, 2>(p, stream);
+        default: return CDX_ENOTSUP;
+    }
+}
 
 int conv_dispatch_small(const ConvParams& p, hipStream_t stream, bool valu_form) {
     dim3 grid(p.tiles_x * p.tiles_y * p.B, 1);

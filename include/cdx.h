@@ -142,6 +142,9 @@ enum {
     CDX_TILE_SMALL = 8,   /* 3x3 stride 1, cout <= 4, width >= 32: 4x4x1-MFMA kernel, 256 pixels  */
     CDX_TILE_SMALL_VALU = 9, /* the same tile on the vector ALU (weights through the scalar cache)  */
     CDX_TILE_CIN8 = 10,   /* 3x3 stride 1, at most 8 input channels (conv_in): 128x128, first channel group only */
+    CDX_TILE_SMALL_GEMM = 12, /* 3x3 stride 1, cout <= 3, ONE source of 64 / 128 / 192 / 256 channels, no upsampling, width >= 32: the taps as
+                               27 GEMM columns of v_mfma_f32_32x32x2_f32 over the pixels of a 16 x 32 tile's halo, activations straight
+                               from memory into the MFMA, the 9 shifted partial sums gathered from LDS: HBM-bound (conv_out)           */
     CDX_TILE_SPLIT = 11   /* v_mfma_f32_32x32x16_f16 with hi/lo split operands (needs wpacked_split and an activation exponent, see
                              cdx_conv_args): 128 px x 128 ch at wout >= 32, 64 x 128 at wout 16..31 and for stride 2 (wout >= 16),
                              64 px x 32 ch with the input chunks split over the waves at wout 8..15 */

@@ -11,10 +11,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,cases,seed", [("fuzz_conv.py", 150, 11), ("fuzz_conv16.py", 100, 12), ("fuzz_attn.py", 80, 13), ("fuzz_unet.py", 8, 14)])
-def test_randomised_conv_sweep(lib, tool, cases, seed):
+@pytest.mark.parametrize("tool,cases,seed,mode", [("fuzz_conv.py", 150, 11, ""), ("fuzz_conv.py", 60, 15, "convout"), ("fuzz_conv16.py", 100, 12, ""),
+                                                  ("fuzz_attn.py", 80, 13, ""), ("fuzz_unet.py", 8, 14, "")])
+def test_randomised_conv_sweep(lib, tool, cases, seed, mode):
     path = os.path.join(ROOT, "tests" if tool == "fuzz_unet.py" else "tools", tool)
-    r = subprocess.run([sys.executable, path, str(cases), str(seed)],
+    r = subprocess.run([sys.executable, path, str(cases), str(seed)] + ([mode] if mode else []),
                        capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail

@@ -50,6 +50,10 @@ CONV_CASES = [
     (2, 8, 128, 36, 40, 3, 1, False),      # conv_in shape: 8 input channels, first-group-only tile (id 10) by default
     (1, 4, 96, 32, 64, 3, 1, False),       # 4 input channels
     (2, 32, 3, 32, 32, 3, 1, False),       # conv_out shape: cout = 3 (vector-ALU kernel, tile 8)
+    (2, 128, 3, 40, 70, 3, 1, False),      # conv_out at 128 channels, ragged in x and y: the GEMM form (tile 12) by default
+    (1, 192, 3, 5, 33, 3, 1, False),       # ... 192 channels (two passes over the tile), image lower than a tile
+    (1, 64, 2, 33, 32, 3, 1, False),       # ... 64 channels, cout = 2
+    (1, 256, 1, 17, 64, 3, 1, False),      # ... 256 channels, cout = 1
     (1, 72, 4, 21, 45, 3, 1, False),       # cout = 4, ragged, Cin not a multiple of the chunk
     (1, 64, 2, 16, 20, 3, 1, True),        # cout = 2 with the fused upsample (40 wide)
     (2, 64, 96, 32, 32, 1, 1, False),      # 1x1
@@ -69,14 +73,15 @@ CONV_CASES = [
 ]
 
 
-def tiles_for(k, s, wout=0, cout=999, cin=1024):
+def tiles_for(k, s, wout=0, cout=999, cin=1024, gemm=False):
     """Every tile shape built for this ksize / stride (include/cdx.h CDX_TILE_*), plus -1 = the library's pick.
-    Tile 7 = Winograd F(2x2,3x3) (3x3 stride 1, output width >= 32)."""
+    Tile 7 = Winograd F(2x2,3x3) (3x3 stride 1, output width >= 32); 12 = cout <= 3 as a GEMM over (tap, cout) columns (`gemm`:
+    the launch has ONE source of 64 / 128 / 192 / 256 channels and no upsampling)."""
     if k == 1:
         return (-1, 0, 1, 2) + ((5, 6) if wout < 32 else ()) + ((11,) if wout >= 8 and cout > 4 and cin % 8 == 0 else ())
     if s == 2:
         return (-1, 3, 4, 5) + ((11,) if wout >= 16 and cout > 4 and cin % 8 == 0 else ())
-    return (-1, 0, 1, 2, 5, 6) + ((8, 9) if wout >= 32 and cout <= 4 else ()) + ((10,) if wout >= 32 and cin <= 8 and cout > 4 else ()) + ((7,) if wout >= 32 else ()) + ((11,) if wout >= 8 and cout > 4 and cin % 8 == 0 else ())     # 7 = Winograd F(2x2,3x3); 11 = split-fp16 operands on the fp16 matrix pipe
+    return (-1, 0, 1, 2, 5, 6) + ((8, 9) if wout >= 32 and cout <= 4 else ()) + ((12,) if gemm and wout >= 32 and cout <= 3 else ()) + ((10,) if wout >= 32 and cin <= 8 and cout > 4 else ()) + ((7,) if wout >= 32 else ()) + ((11,) if wout >= 8 and cout > 4 and cin % 8 == 0 else ())     # 7 = Winograd F(2x2,3x3); 11 = split-fp16 operands on the fp16 matrix pipe
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
@@ -89,7 +94,7 @@ def test_conv_plain(cdx_mod, case):
     want = F.conv2d(xin, w.double(), bias.double(), stride=s, padding=k // 2)
     pc = cdx_mod.ops.PackedConv(w.numpy(), bias.numpy(), ci)
     xd = nhwc(x)
-    for tile in tiles_for(k, s, want.shape[-1], co, ci):
+    for tile in tiles_for(k, s, want.shape[-1], co, ci, gemm=not up and ci in (64, 128, 192, 256)):
         got = nchw(cdx_mod.ops.conv(pc, xd, stride=s, upsample=up, tile=tile))
         assert got.shape == want.shape
         close(got, want, 4e-6 if tile == 7 else 2e-6, f"conv tile {tile}")
@@ -102,7 +107,10 @@ def test_conv_plain(cdx_mod, case):
     (1, 128, 64, 96, 8, 8, 32),       # concat, 6 channels / group
     (2, 32, 0, 32, 4, 4, 8),
     (1, 64, 32, 3, 40, 64, 32),       # conv_out-like: cout = 3, concat, vector-ALU kernel
-    (2, 128, 0, 3, 32, 32, 32),       # conv_out proper
+    (2, 128, 0, 3, 32, 32, 32),       # conv_out proper (GEMM form, tile 12, by default)
+    (1, 192, 0, 3, 50, 45, 32),       # ... at 192 channels (cfg4), ragged
+    (1, 256, 0, 2, 20, 64, 32),
+    (2, 64, 0, 1, 35, 33, 16),
 ])
 def test_conv_fused_gn_silu_concat_temb_residual(cdx_mod, B, c0, c1, co, H, W, groups):
     """The whole first half of a ResBlock in one launch pair: conv3x3(silu(gn(cat[x, skip]))) + bias +
@@ -125,7 +133,7 @@ def test_conv_fused_gn_silu_concat_temb_residual(cdx_mod, B, c0, c1, co, H, W, g
     close(mean.cpu(), xg.mean(-1), 1e-6, "gn mean")
     close(rstd.cpu(), (xg.var(-1, unbiased=False) + 1e-5).rsqrt(), 1e-6, "gn rstd")
     pc = ops.PackedConv(w.numpy(), bias.numpy(), c0, c1)
-    for tile in tiles_for(3, 1, W, co):
+    for tile in tiles_for(3, 1, W, co, gemm=not c1 and c0 in (64, 128, 192, 256)):
         got = nchw(ops.conv(pc, s0, s1, gn=(sc, sh), silu=True, temb=temb.cuda(), temb_off=2, residual=nhwc(res), tile=tile))
         close(got, want, 5e-6 if tile == 7 else 3e-6, f"fused conv tile {tile}")
 

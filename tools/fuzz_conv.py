@@ -3,7 +3,7 @@
 random layer shapes (incl. ragged sizes, concat, upsample, stride 2, 1x1, tiny / huge channel counts), random fusion
 flags (GroupNorm+SiLU on load, temb, residual, GroupNorm sums of the output) and -- VERDICT r02 item 1 -- a random
 log-uniform SCALE per source (10^U(-6, 6)): the error is judged relative to the output's own scale, no floor.
-usage: tools/fuzz_conv.py [cases] [seed]"""
+usage: tools/fuzz_conv.py [cases] [seed] [convout]      (convout: only layers the cout <= 3 GEMM form, tile 12, can take)"""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.nn.functional as F
@@ -12,6 +12,7 @@ from cdx import ops, _abi
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+convout = len(sys.argv) > 3 and sys.argv[3] == "convout"
 nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
 nchw = lambda t: t.permute(0, 3, 1, 2).contiguous().cpu()
 bad, tiles_seen = 0, {}
@@ -28,6 +29,10 @@ for case in range(ncases):
     c0 = int(rng.choice([32, 64, 96, 128])) if concat else int(rng.choice([4, 8, 12, 32, 40, 64, 72, 128, 160]))
     c1 = int(rng.choice([32, 64])) if concat else 0
     co = int(rng.choice([1, 2, 3, 4, 8, 32, 48, 64, 96, 128, 160, 200, 256]))
+    if convout:      # 3x3 stride 1, ONE source of 64 / 128 / 192 / 256 channels, cout <= 3, at least 32 pixels wide, any height
+        k, s, up, concat, c1 = 3, 1, False, False, 0
+        c0, co = int(rng.choice([64, 128, 192, 256])), int(rng.integers(1, 4))
+        H, W = int(rng.integers(1, 41)), int(rng.integers(32, 101))
     ci = c0 + c1
     groups = 4 if ci % 32 else 32
     gn = bool(rng.integers(0, 2)) and ci % groups == 0
