@@ -204,7 +204,7 @@ def measure_dominant_kernel(plan, torch, reps=3, workload="cfg2"):
             "frac": round(algorithmic / peak, 4), "traffic": None,
             "frac_algorithmic": round(algorithmic / peak, 4),
             "emulation_factor": ef, "mfma_pipe_utilisation": round(executed / peak, 4), "executed_tflops": round(executed, 2),
-            "kernel": km["name"] + " [ksize %d stride %d log2TW %d tile %s]" % dom,
+            "kernel": km["name"] + " [ksize %d stride %d layers >= 2^%d px wide, tile id %s; 3x3 stride 1 at >= 32 px runs 8 x 16-pixel tiles]" % dom,
             "flop_accounting": "achieved / frac / frac_algorithmic = algorithmic (direct-convolution) FLOPs 2*Cin*Cout*k*k*H*W*B per second "
                                "against the dense peak of the MFMA instruction the kernel issues; executed_tflops / mfma_pipe_utilisation = "
                                "the MFMA FLOPs it actually issues (emulation_factor x algorithmic) against the same peak"
