@@ -127,6 +127,7 @@ def kernel_model(variant) -> dict:
                 # rocprofv3 kernel-name substring of this variant (every staging mode STG of it): KS, ST, log2TW, MT, PF, ABL, SPLIT, DB, BF
                 # (3x3 stride 1 at >= 32 px: the wave-specialised 8-wave workgroup, WS = 1 -- conv16_ws_kernel)
                 "pmc_pattern": ("Conv16Cfg<3, 1, 4, 4, 3, 0, 1, 1, 0, 1>" if variant[:3] == (3, 1, 5) else      # (8 x 16-pixel tile: template LOGTW = 4, MT = 4)
+                                "Conv16Cfg<3, 1, 4, 2, 3, 0, 1, 1, 0, 1>" if variant[:3] == (3, 1, 4) else                       # (16 px wide: wave-specialised 64-pixel tile)
                                 "Conv16Cfg<%d, %d, %d, %d, 3, 0, 1, %d, 0, 0>" % (variant[0], variant[1], variant[2], 2 if (variant[1] == 2 or variant[2] < 5) else 4, 0 if variant[1] == 2 else 1))}
     if tile.startswith("f16"):
         return {"name": "conv16_kernel<Conv16Cfg> (v_mfma_f32_32x32x16_f16)", "executed_per_algorithmic": 1.0,

@@ -332,34 +332,44 @@ __global__ __launch_bounds__(256, 2) void conv_small_gemm_kernel(const ConvParam
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             int fresh = 0;                                   // (opaque: scale / shift are re-read from LDS per block -- hoisted out of
             asm volatile("" : "+v"(fresh));                  //  the loop they would pin 32 registers per 32 channels)
-#pragma unroll
-            for (int J = 0; J < NJH; ++J) {
-                f32x4 v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(ssc + fresh + 32 * J + 4 * i);
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(ssh + fresh + 32 * J + 4 * i);
-                    v[i] = x[J][i];
-                    if constexpr (!(ABL & 4)) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[i][e] = fmaf(v[i][e], sc[e], sh[e]);
-                            if constexpr (SILU) v[i][e] = silu_f<false>(v[i][e]);
-                            v[i][e] = inimg ? v[i][e] : 0.f;        // zero padding of the ACTIVATED tensor (and NaN-free dummy reads)
-                        }
-                    }
-                }
-                if (more) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) x[J][i] = *reinterpret_cast<const f32x4*>(pn + 32 * J + 4 * i);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
+            // step (J, i) = 4 channels per lane = 4 MFMAs.  The vector work of step t + 1 stands BETWEEN the MFMA groups of steps
+            // t - 1 and t in program order (a wave issues in order: with all of a J's arithmetic ahead of its 16 MFMAs the matrix
+            // pipe idled through it -- same-box A/B of whole steps: 22.24 -> 22.20 ms at configs[1])
+            auto act = [&](int J, int i) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(ssc + fresh + 32 * J + 4 * i);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(ssh + fresh + 32 * J + 4 * i);
+                f32x4 v = x[J][i];
+                if constexpr (!(ABL & 4)) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if constexpr (ABL & 1) acc[e] = fmaf(v[i][e], wreg[J][i][e], acc[e]);      // (ABL 1: no MFMA)
-                        else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i][e], wreg[J][i][e], acc, 0, 0, 0);
+                        v[e] = fmaf(v[e], sc[e], sh[e]);
+                        if constexpr (SILU) v[e] = silu_f<false>(v[e]);
+                        v[e] = inimg ? v[e] : 0.f;                  // zero padding of the ACTIVATED tensor (and NaN-free dummy reads)
                     }
+                }
+                return v;
+            };
+            f32x4 vc = act(0, 0);
+#pragma unroll
+            for (int J = 0; J < NJH; ++J) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 vn = vc;
+                    const int t = J * 4 + i + 1;
+                    if (t < NJH * 4) vn = act(t >> 2, t & 3);
+                    if (i == 3 && more) {                           // x[J] is free: refill it for the next block
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii) x[J][ii] = *reinterpret_cast<const f32x4*>(pn + 32 * J + 4 * ii);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (ABL & 1) acc[e] = fmaf(vc[e], wreg[J][i][e], acc[e]);      // (ABL 1: no MFMA)
+                        else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[e], wreg[J][i][e], acc, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    vc = vn;
+                }
             }
             in_cur = in_next;
             // lane (n, half), register r -> Y[pixel 32 blk + 8 (r / 4) + 4 half + (r & 3)][n]; later passes add (same lane, same word)

@@ -224,7 +224,9 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     }
     if (logtw == 4) {      // 16 pixels wide: 64 pixels x 128 channels (measured at 16^2 x 512, batch 16: 0.93 ms per forward for the
         // 3x3 layers against 0.98 with the chunk-parallel tile, whose waves each stage a whole chunk for 32 channels)
-        if (a->ksize == 3) return conv16_launch<Conv16Cfg<3, 1, 4, 2, 3, 0, 1>>(p, stream);
+        // (wave-specialised like the 128-pixel tile: 256 workgroups of a batch-16 level at 16^2 are ONE per CU, so the 4 producer
+        // waves are the only thing that can stage under the MFMAs -- same-box A/B of whole steps: cfg2 22.24 -> 22.15 ms)
+        if (a->ksize == 3) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 2, 3, 0, 1, 1, 0, 1>>(p, stream);
         return conv16_launch<Conv16Cfg<1, 1, 4, 2, 3, 0, 1>>(p, stream);
     }
     if (logtw == 3) {      // 8 pixels wide: 64 pixels x 32 channels per workgroup, the 4 waves split the input chunks
