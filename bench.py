@@ -30,7 +30,12 @@ Extra objects on the JSON line:
   strict_f32   -- the same step loop on the f32-input MFMA kernels only (UNet(split=False): direct + Winograd
                   v_mfma_f32_32x32x2_f32), a few steps, timed in the same run: the conservative float32 number.
   cpu_baseline -- the stock-torch CPU oracle (oracle/, kind "port": the reference ships no sampler) timed
-                  on this host's cores on a bounded sample of the same workload (rank 0, N = 1 only).
+                  on this host's cores on a bounded sample of the same workload (rank 0, N = 1 only): image 0 of the job, all of
+                  its steps when they fit --cpu-budget (cfg2: 100 steps, ~60-75 s on 16 cores).
+  parity       -- the metric's second half ("PSNR delta vs ref"): the HIP decode of image 0 (from the Sampler.sample call timed
+                  as sample_call) against the oracle's decode of the same image from the cpu_baseline leg: PSNR(hip, oracle),
+                  |PSNR(hip, target) - PSNR(oracle, target)|, max abs error, steps compared.  bench.py exits non-zero when
+                  PSNR(hip, oracle) < 80 dB or the delta exceeds 0.01 dB (--no-parity-gate: report only).
 """
 from __future__ import annotations
 
@@ -201,7 +206,8 @@ def measure_dominant_kernel(plan, torch, reps=3, workload="cfg2"):
     # achieved = ALGORITHMIC FLOPs of the launches / their measured time; frac = achieved / peak of the pipe the
     # kernel runs on.  A kernel that emulates float32 products with 3 fp16 MFMAs (emulation_factor 3) can reach at most 1/3 of
     # that peak in algorithmic terms; mfma_pipe_utilisation = executed MFMA FLOPs / peak says how busy it keeps the pipe.
-    roof = {"bound": "mfma", "achieved": round(algorithmic, 2), "peak": peak, "unit": "TFLOP/s",
+    roof = {"roofline_schema": 2,    # 1 (rounds 1-2): frac = EXECUTED MFMA FLOPs / peak; 2 (round 3 on): frac = ALGORITHMIC FLOPs / peak
+            "bound": "mfma", "achieved": round(algorithmic, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(algorithmic / peak, 4), "traffic": None,
             "frac_algorithmic": round(algorithmic / peak, 4),
             "emulation_factor": ef, "mfma_pipe_utilisation": round(executed / peak, 4), "executed_tflops": round(executed, 2),
@@ -254,8 +260,11 @@ def host_cores() -> int:
     return int(env) if env else min(n, 16)
 
 
-def cpu_baseline(cfg, run, params, cond_cpu, torch, budget_s=25.0):
-    """Stock-torch CPU oracle: seconds per UNet forward + update at batch 1 (one image / one tile), bounded sample."""
+def cpu_baseline(cfg, run, params, cond_cpu, torch, budget_s=300.0):
+    """Stock-torch CPU oracle on image 0 of the job (same cond, x_T stream and per-step noise streams as the GPU's image 0):
+    seconds per UNet forward + update at batch 1, on as many of the run's steps as fit into budget_s (default: all of them for
+    cfg2: ~0.6 s/step).  Returns (the cpu_baseline object, the oracle's state after the last step it ran [1,3,H,H] -- clamped if
+    that was the run's final step --, the number of steps it ran)."""
     import oracle
     ncores = host_cores()
     torch.set_num_threads(ncores)
@@ -274,16 +283,44 @@ def cpu_baseline(cfg, run, params, cond_cpu, torch, budget_s=25.0):
         times.append(time.perf_counter() - t0)
         if k >= 1 and time.perf_counter() - t_begin > budget_s:
             break
+    done = len(times)
+    if done == S:
+        x = x.clamp(-1.0, 1.0)
     timed = times[1:] if len(times) > 1 else times    # first step = warm-up
     sec_per_step = sum(timed) / len(timed)
     tiles = 1
     if "image" in run:
         import cdx
         tiles = len(cdx.tile_origins(run["image"], H, run["overlap"])) ** 2
-    return {"value": round(1.0 / (sec_per_step * S * tiles), 6), "unit": "images/s", "cores": ncores, "kind": "port",
-            "sample": f"1 image x {len(timed)} of {S} {run['method'].upper()} steps at {H}x{H} (1 warm-up step dropped; every step "
-                      f"costs the same), scaled to {S} steps" + (f" x {tiles} tiles per {run['image']}^2 image" if tiles > 1 else "")
-                      + f"; {sec_per_step:.2f} s/step, float32, torch {torch.__version__} CPU"}
+    return ({"value": round(1.0 / (sec_per_step * S * tiles), 6), "unit": "images/s", "cores": ncores, "kind": "port",
+             "sample": f"1 image x {len(timed)} of {S} {run['method'].upper()} steps at {H}x{H} (1 warm-up step dropped; every step "
+                       f"costs the same), scaled to {S} steps" + (f" x {tiles} tiles per {run['image']}^2 image" if tiles > 1 else "")
+                       + f"; {sec_per_step:.2f} s/step, float32, torch {torch.__version__} CPU"}, x, done)
+
+
+PARITY_MIN_PSNR_DB = 80.0     # gate 2 (build-imposed): PSNR(hip, oracle), peak-to-peak 2.0
+PARITY_MAX_DPSNR_DB = 0.01    # gate 1 (BASELINE.json north_star): |PSNR(hip, target) - PSNR(oracle, target)|
+
+
+def psnr_db(a, b) -> float:
+    import math
+    mse = ((a.double() - b.double()) ** 2).mean().item()
+    return float("inf") if mse == 0 else 10.0 * math.log10(4.0 / mse)
+
+
+def parity_object(hip, oracle_x, target, steps_done, steps_total, how) -> dict:
+    """The metric's second half ("PSNR delta vs ref", SURVEY.md 8d gates 1-2) for image 0: the HIP decode against the CPU oracle's
+    decode of the same image (same cond, x_T, weights).  `complete` = the oracle ran every step (states compared are then the
+    final clamped images; otherwise the x_t after `steps` reverse steps)."""
+    hip, oracle_x, target = hip.detach().float().cpu(), oracle_x.float().cpu(), target.float().cpu()
+    p_ho, p_ht, p_ot = psnr_db(hip, oracle_x), psnr_db(hip, target), psnr_db(oracle_x, target)
+    complete = steps_done == steps_total
+    ok = p_ho >= PARITY_MIN_PSNR_DB and (not complete or abs(p_ht - p_ot) <= PARITY_MAX_DPSNR_DB)
+    return {"psnr_hip_vs_oracle_db": round(p_ho, 3), "psnr_delta_vs_target_db": round(abs(p_ht - p_ot), 7),
+            "psnr_hip_vs_target_db": round(p_ht, 5), "psnr_oracle_vs_target_db": round(p_ot, 5),
+            "max_abs_err": float((hip - oracle_x).abs().max().item()), "steps": steps_done, "of_steps": steps_total, "complete": complete,
+            "image": 0, "hip_image_from": how, "oracle": "oracle.unet_forward_ref + update on the CPU, float32 (PARITY UNPINNED by the reference: it ships no sampler)",
+            "gates": {"psnr_hip_vs_oracle_db_min": PARITY_MIN_PSNR_DB, "psnr_delta_vs_target_db_max": PARITY_MAX_DPSNR_DB}, "pass": bool(ok)}
 
 
 def free_port() -> int:
@@ -321,16 +358,28 @@ def strict_f32_leg(cdx, torch, job, cfg, run, B, tiles_per_image, total_flops, t
     ms = sec / nsteps * 1e3
     tf = total_flops / (ms * 1e-3) / 1e12
     out = {"images_per_s": round((B / tiles_per_image) / (run["steps"] * ms * 1e-3), 4), "ms_per_step": round(ms, 3), "steps": nsteps,
-           "algorithmic_tflops_whole_step": round(tf, 2), "frac_of_f32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "peak": FP32_MFMA_PEAK_TFLOPS,
+           "algorithmic_tflops_whole_step": round(tf, 2), "algorithmic_over_direct_f32_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "peak": FP32_MFMA_PEAK_TFLOPS,
            "arithmetic": "float32 operands on v_mfma_f32_32x32x2_f32 (direct + Winograd F(2x2,3x3): algorithmic rate can exceed the direct-convolution peak)"}
     del smp, st, net
     torch.cuda.empty_cache()
     return out
 
 
-def main(argv=None, make_sampler=None, dist_backend="nccl"):
-    """make_sampler / dist_backend: test injection (tests/bench_entry_oracle.py runs this same function on CPU ranks over gloo
-    with a stand-in sampler to exercise the launch, shard and timing path without a GPU); the product run passes neither."""
+def bind_gpu(torch, local: int) -> str:
+    """One process per GPU: the rank whose LOCAL_RANK is l drives cuda:l (and nothing else)."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    return f"cuda:{local}"
+
+
+def main(argv=None, make_sampler=None, dist_backend=None, bind_device=None):
+    """make_sampler: test injection (tests/bench_entry_oracle.py runs this same function on CPU ranks with a stand-in sampler to
+    exercise the launch, shard and timing path without a GPU); the product run passes none.  dist_backend overrides
+    --dist-backend.  The control plane (barrier + max-over-ranks of one float64) runs over GLOO on CPU tensors by default, in
+    the product run too: the data path has no collective (north_star: "no RCCL required"), and gloo is the backend the CPU
+    tests exercise; `--dist-backend nccl` initialises RCCL for the same two calls instead.  bind_device (default: not injected):
+    bind this rank to cuda:LOCAL_RANK (the 8-rank CPU rehearsal passes True with torch.cuda mocked to check the binding)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -339,6 +388,9 @@ def main(argv=None, make_sampler=None, dist_backend="nccl"):
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--graph", action="store_true", help="replay each UNet forward as one hipGraph launch (Sampler(use_graph=True): host-bound sizes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=200.0, help="seconds of CPU-oracle work in the cpu_baseline / parity leg (cfg2's 100 steps need ~60-75 s on 16 cores)")
+    ap.add_argument("--no-parity-gate", action="store_true", help="report the parity object but do not exit non-zero when it fails its gates")
+    ap.add_argument("--dist-backend", default="gloo", choices=["gloo", "nccl"], help="control plane of a multi-rank run (barrier + max-reduce only)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sample-call", action="store_true", help="skip the extra timing of one complete Sampler.sample()")
     ap.add_argument("--no-strict-f32", action="store_true", help="skip the extra step loop on the f32-input MFMA kernels (strict_f32)")
@@ -360,30 +412,30 @@ def main(argv=None, make_sampler=None, dist_backend="nccl"):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not injected:
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-        torch.cuda.set_device(local)
+    if bind_device if bind_device is not None else not injected:
+        bind_gpu(torch, local)
     dist = None
-    if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run: RCCL for the barrier / max-reduce only
+    backend = dist_backend or args.dist_backend
+    if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run: a process group for the barrier / max-reduce only
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if injected:
-            dist.init_process_group(dist_backend)
+        if backend == "nccl" and not injected:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
-            dist.init_process_group(dist_backend, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend)
 
     # This rank's shard of the job: weak scaling, B units per GPU (cdx.shard owns the rank arithmetic).
     cfg, run = cdx.named_config(args.config)
     if args.dtype:
         cfg = cdx.unet_config(**dict(cfg, dtype=args.dtype))
-    B = args.batch or {"cfg5": 16}.get(args.config, cdx.shard.IMAGES_PER_CALL[args.config])
     tiled = "image" in run
+    per_gpu = cdx.shard.IMAGES_PER_CALL[args.config]          # images of the job per GPU (BASELINE.json: 16 / 16 / 8 / 8)
+    B = args.batch or (16 if tiled else per_gpu)              # units per sampler step and GPU: images, or (cfg5) TILES
     tiles_per_image = len(cdx.tile_origins(run["image"], cfg["image_size"], run["overlap"])) ** 2 if tiled else 1
-    images_per_gpu = 1 if tiled else B            # cfg5: the step loop runs B TILES; sample_call decodes one whole image
+    images_per_gpu = per_gpu if tiled else B      # cfg5: the step loop runs B TILES per step; sample_call decodes the rank's whole images
     device = None if injected else f"cuda:{local}"
     job = cdx.shard.ShardJob(images_per_gpu * world, args.config, rank=rank, world=world, device=device,
-                             images_per_call=images_per_gpu, config=(cfg, run), unet_kw={"split": False} if args.no_split else None,
+                             images_per_call=1 if tiled else images_per_gpu, config=(cfg, run), unet_kw={"split": False} if args.no_split else None,
                              make_sampler=make_sampler)
     sampler = job.sampler
     net = getattr(sampler, "unet", None)
@@ -392,7 +444,8 @@ def main(argv=None, make_sampler=None, dist_backend="nccl"):
 
     # inputs resident in HBM before the timed region: Sampler.begin() loads cond and draws x_T
     if tiled:
-        conds, xts, _, _ = cdx.tiling.tile_batch(net, job.cond(job.lo, 1), run["overlap"], job.seed, job.lo)
+        tile_batch = getattr(sampler, "tile_batch", None) or (lambda cond, overlap, seed, first: cdx.tiling.tile_batch(net, cond, overlap, seed, first))
+        conds, xts, _, _ = tile_batch(job.cond(job.lo, 1), run["overlap"], job.seed, job.lo)
         reps_ = -(-B // conds.shape[0])
         state = sampler.begin(conds.repeat(reps_, 1, 1, 1)[:B].contiguous(), run["steps"], seed=job.seed,
                               x_T=xts.repeat(reps_, 1, 1, 1)[:B].contiguous())
@@ -429,23 +482,25 @@ def main(argv=None, make_sampler=None, dist_backend="nccl"):
                                 f"{cfg['dtype']}, cond_mode {cfg['cond_mode']}, {run['steps']}-step {run['method'].upper()}, "
                                 f"batch {B} per GPU" + (f" = tiles of a {run['image']}^2 image ({tiles_per_image} tiles/image, "
                                                        f"overlap {run['overlap']})" if tiled else "")),
-                   "images_per_gpu": B / tiles_per_image, "global_batch": B * world, "image": f"{cfg['image_size']}x{cfg['image_size']}x3",
+                   "images_per_gpu": images_per_gpu, "global_batch": images_per_gpu * world,
+                   "units_per_step_per_gpu": B, "unit_of_a_step": "tile" if tiled else "image",
+                   "image": f"{run.get('image', cfg['image_size'])}x{run.get('image', cfg['image_size'])}x3",
                    "sampler_steps_per_image": run["steps"], "parallelism": f"replica x{world} (no collective)",
                    "timed": "Sampler.step() x steps (cdx.sampler), shard + timing from cdx.shard.ShardJob / timed_region"
                             + (", UNet forward replayed as one hipGraph per step" if args.graph else "")},
         "algorithmic_gflop_per_step": round(total_flops / 1e9, 1),
         "algorithmic_tflops_whole_step": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
     }
+    out = {}
     if not args.no_sample_call:
         # ONE complete decode of this rank's shard through the API entry point itself: Sampler.sample (cfg5:
-        # Sampler.sample_tiled of one whole image) -- x_T draw, every step, export; max over ranks.
-        out = {}
+        # Sampler.sample_tiled of each of the rank's whole images, 16 tiles per call) -- x_T draw, every step, export; max over ranks.
         sec = cdx.timed_region(lambda: out.update(job.decode()), dist, sync)
         n_img = images_per_gpu * world
         line["sample_call"] = {"entry": "Sampler.sample_tiled(cond, steps)" if tiled else "Sampler.sample(cond, steps)",
                                "images": n_img, "steps": run["steps"], "seconds": round(sec, 4),
                                "images_per_s": round(n_img / sec, 4),
-                               "ms_per_step_equiv": round(sec * 1e3 / (run["steps"] * (-(-tiles_per_image // B) if tiled else 1)), 3)}
+                               "ms_per_step_equiv": round(sec * 1e3 / (run["steps"] * (-(-tiles_per_image // 16) * images_per_gpu if tiled else 1)), 3)}
         assert all(torch.isfinite(v).all() for v in out.values())
     if injected:
         line["backend"] = "injected sampler (test of the launch / shard / timing path; not a measurement of the product)"
@@ -460,12 +515,31 @@ def main(argv=None, make_sampler=None, dist_backend="nccl"):
         c1 = job.cond(0, 1).cpu()
         if tiled:
             c1 = c1[..., :cfg["image_size"] // 16, :cfg["image_size"] // 16].contiguous()
-        line["cpu_baseline"] = cpu_baseline(dict(cfg, dtype="fp32"), run, job.params, c1, torch)
+        line["cpu_baseline"], x_cpu, done = cpu_baseline(dict(cfg, dtype="fp32"), run, job.params, c1, torch, budget_s=args.cpu_budget)
+        if tiled:
+            line["parity"] = {"skipped": "tiled configuration: the CPU leg decodes one tile with its own x_T; the whole-image parity "
+                                         "check is tests/test_configs_gpu.py (25 fp16 tiles vs the oracle blend)"}
+        else:
+            # the metric's second half: the HIP decode of image 0 against the oracle's decode of the same image.  If the oracle ran all
+            # steps and sample_call decoded this shard, the HIP image is image 0 of THAT Sampler.sample call; otherwise image 0 is
+            # decoded again alone with a trace (bit-identical to its in-batch decode: tests/test_e2e_gpu.py sharding invariance).
+            S = run["steps"]
+            if done == S and 0 in out:
+                hip, how = out[0][None], "image 0 of the Sampler.sample(cond, steps) call timed as sample_call"
+            else:
+                trace = []
+                fin = sampler.sample(job.cond(0, 1), S, seed=job.seed, first_image=0, trace=trace)
+                hip = fin if done == S else trace[done - 1]
+                how = f"Sampler.sample(cond[0:1], {S}, trace=...) state after step {done}"
+            line["parity"] = parity_object(hip, x_cpu, torch.from_numpy(job.inputs(0, 1)["target"]), done, S, how)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(line), flush=True)
+        par = line.get("parity")
+        if par and par.get("pass") is False and not args.no_parity_gate:
+            raise SystemExit(f"parity gate failed: {par}")
 
 
 if __name__ == "__main__":

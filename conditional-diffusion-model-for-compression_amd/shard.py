@@ -88,7 +88,6 @@ class ShardJob:
                  seed: int = 0, images_per_call: int | None = None, steps: int | None = None, make_sampler=None,
                  config: tuple[dict, dict] | None = None, params: dict | None = None, unet_kw: dict | None = None):
         from .config import named_config
-        from .params import init_params
         self.cfg, self.run = config if config is not None else named_config(cfg_name)
         self.cfg_name, self.rank, self.world, self.seed = cfg_name, rank, world, seed
         self.total = self.run["batch"] if total_images is None else total_images
@@ -97,9 +96,18 @@ class ShardJob:
         self.images_per_call = images_per_call or IMAGES_PER_CALL.get(cfg_name, 1)
         self.tiled = "image" in self.run
         self.device = device
-        self.params = init_params(dict(self.cfg, dtype="fp32"), seed) if params is None else params
-        self.sampler = (make_sampler(self.cfg, self.run, self.params, device) if make_sampler is not None else
+        self._params = params
+        needs = getattr(make_sampler, "needs_params", True)      # a stand-in that ignores the weights need not have them drawn
+        self.sampler = (make_sampler(self.cfg, self.run, self.params if needs else None, device) if make_sampler is not None else
                         _hip_sampler(self.cfg, self.run, self.params, device, **(unet_kw or {})))
+
+    @property
+    def params(self) -> dict:
+        """The seeded synthetic weights (params.init_params), drawn on first use."""
+        if self._params is None:
+            from .params import init_params
+            self._params = init_params(dict(self.cfg, dtype="fp32"), self.seed)
+        return self._params
 
     # ---- inputs: synthetic, keyed by the GLOBAL image index (params.synthetic_batch) ----
     def inputs(self, first: int, count: int) -> dict:

@@ -31,6 +31,30 @@ def test_two_ranks_through_the_self_launch_path_print_one_line():
     assert abs(d["value"] - 2 / (50 * d["ms_per_step"] * 1e-3)) <= 2e-3 * d["value"]
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("config,global_batch,per_rank,image", [("cfg3", 128, 16, "256x256x3"), ("cfg5", 64, 8, "1024x1024x3")])
+def test_eight_rank_rehearsal_of_the_driver_command(tmp_path, config, global_batch, per_rank, image):
+    """The command the driver runs on the 8-GPU node (`bench.py --gpus 8`, here for the job shapes of BASELINE.json configs[2] and
+    configs[4]) rehearsed with 8 CPU ranks: the self-launch path, the gloo control plane bench.py uses in the product run too,
+    cdx.shard's rank arithmetic at the real sizes, ONE JSON line -- and every rank binds cuda:LOCAL_RANK (torch.cuda mocked)."""
+    argv = ["--gpus", "8", "--config", config, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.launch_ranks(8, %r, entry=%r))" % (ROOT, argv, os.path.join(ROOT, "tests", "bench_entry_oracle.py")))
+    env = dict(os.environ, CDX_BENCH_STANDIN="null", CDX_BENCH_BIND_LOG=str(tmp_path), OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=540, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert KEYS <= set(d)
+    c = d["config"]
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and c["global_batch"] == global_batch and c["images_per_gpu"] == per_rank
+    assert c["image"] == image and "x8" in c["parallelism"] and "injected" in d["backend"]
+    assert d["sample_call"]["images"] == global_batch
+    binds = sorted(open(os.path.join(tmp_path, f)).read() for f in os.listdir(tmp_path))
+    assert binds == ["%d %d" % (r_, r_) for r_ in range(8)], binds      # rank r (single node: LOCAL_RANK r) -> cuda:r
+
+
 @pytest.mark.timeout(300)
 def test_plain_multi_gpu_command_launches_children_and_propagates_failure():
     """No GPU in this container: the children exit with an error, and so must the parent -- without a JSON line."""

@@ -176,6 +176,45 @@ def test_benchmark_config_full_size_vs_live_oracle(cdx_mod, record, split):
     assert psnr(got, want) >= 80.0 and abs(psnr(got, tgt) - psnr(want, tgt)) <= 0.01
 
 
+_CFG2_FULL = {}
+
+
+def _cfg2_full_oracle(cdx_mod, cfg, params, picks, steps):
+    """The CPU oracle's complete decode of the picked cfg2 images as ONE batch (x_T from each image's own global stream;
+    DDIM draws no step noise), ~1 s per step on the GPU box's 16 cores; computed once for both conv paths."""
+    import oracle
+    if "x" not in _CFG2_FULL:
+        H = cfg["image_size"]
+        sb = [cdx_mod.synthetic_batch(cfg, 0, i, 1) for i in picks]
+        cond = torch.from_numpy(np.concatenate([b["cond"] for b in sb]))
+        x_T = torch.cat([oracle.sampler_ref.noise_ref(0, i, 1, 1, (3, H, H)) for i in picks])
+        torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+        _CFG2_FULL["x"] = oracle.sample_ref(cfg, params, cond, steps, seed=0, x_T=x_T)
+        _CFG2_FULL["target"] = torch.from_numpy(np.concatenate([b["target"] for b in sb]))
+    return _CFG2_FULL["x"], _CFG2_FULL["target"]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("split", [True, False])
+def test_headline_config_100_steps_full_size_vs_live_oracle(cdx_mod, record, split):
+    """THE headline workload end to end (BASELINE.json configs[1]): 256x256, the 113.7 M-parameter UNet with
+    bench.py's weights, the whole batch of 16 decoded by ONE Sampler.sample(cond, 100) call -- all 100 DDIM steps -- and images 0
+    and 15 of it compared with the CPU oracle's 100-step decode of the same two images: both PSNR gates, on both conv paths."""
+    cfg, run = cdx_mod.named_config("cfg2")
+    assert run["steps"] == 100 and run["batch"] == 16
+    params = cdx_mod.init_params(cfg, seed=0)
+    picks = (0, 15)
+    want, tgt = _cfg2_full_oracle(cdx_mod, cfg, params, picks, run["steps"])
+    cond = torch.from_numpy(cdx_mod.synthetic_batch(cfg, 0, 0, 16)["cond"]).cuda()
+    got = cdx_mod.Sampler(cdx_mod.UNet(cfg, params, split=split)).sample(cond, run["steps"], seed=0).cpu()[list(picks)]
+    assert torch.isfinite(got).all() and got.abs().max().item() <= 1.0
+    for j, i in enumerate(picks):
+        p, dp = psnr(got[j], want[j]), abs(psnr(got[j], tgt[j]) - psnr(want[j], tgt[j]))
+        record("sampler_cfg2_100_steps" + ("" if split else "_f32mfma"), image=i, psnr_hip_vs_oracle=p, dpsnr=dp,
+               max_err=(got[j] - want[j]).abs().max().item())
+        assert p >= 80.0 and dp <= 0.01, (i, p, dp)
+
+
 def test_sampler_ddpm_golden(cdx_mod, record):
     """Ancestral sampling (fresh device noise every step) against the committed oracle output."""
     g = np.load(os.path.join(GOLD, "tiny_ddpm.npz"))
