@@ -240,12 +240,38 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                 reinterpret_cast<unsigned long long*>(p.stats)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 16 + k] = t;
         }
     };
-    stamp(0);
+    // (WS, ABL & 512) barrier accounting: ticks a wave spends inside the per-chunk __syncthreads (slot 15 of an MFMA wave; the
+    // producers write their own rows behind the MFMA waves': 0 entry, 1 ticks at barriers, 2 ticks staging, 3 exit) -- tools/ws_stamps.py
+    auto memtime = [&]() __attribute__((always_inline)) {
+        unsigned long long t = 0;
+        if constexpr ((C::ABL & 512) != 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return t;
+    };
+    unsigned long long bar_ticks = 0, stage_ticks = 0;
+    auto timed_barrier = [&]() __attribute__((always_inline)) {
+        if constexpr (C::WS && (C::ABL & 512) != 0) {
+            const unsigned long long t0 = memtime();
+            __syncthreads();
+            bar_ticks += memtime() - t0;
+        } else {
+            __syncthreads();
+        }
+    };
+    if (!producer) stamp(0);
+    if constexpr ((C::ABL & 512) != 0) {
+        if (producer) {
+            if (lane == 0) reinterpret_cast<unsigned long long*>(p.stats)[((size_t)(gridDim.y * gridDim.x + blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 16 + 0] = memtime();
+        }
+    }
     if constexpr ((C::ABL & 512) != 0) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        if (lane == 0) {
+        if (lane == 0 && !producer) {
             reinterpret_cast<unsigned long long*>(p.stats)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 16 + 13] = hw;
             reinterpret_cast<unsigned long long*>(p.stats)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 16 + 14] = xcc;
         }
@@ -405,11 +431,18 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             for (int chunk = 0; chunk < p.nchunks; ++chunk) {
                 H* nxt = lds_all + ((chunk + 1) & 1) * C::LDS_HALVES;
                 if (chunk + 1 < p.nchunks && !(C::ABL & 2)) {
+                    const unsigned long long t0 = memtime();
 #pragma unroll
                     for (int i = 0; i < NPASS; ++i) write_pass(nxt, i);
                     if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
+                    stage_ticks += memtime() - t0;
                 }
-                __syncthreads();
+                timed_barrier();
+            }
+            if constexpr ((C::ABL & 512) != 0) {
+                unsigned long long* row = reinterpret_cast<unsigned long long*>(p.stats) + ((size_t)(gridDim.y * gridDim.x + blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 16;
+                const unsigned long long te = memtime();
+                if (lane == 0) { row[1] = bar_ticks; row[2] = stage_ticks; row[3] = te; }
             }
             return;
         }
@@ -442,13 +475,29 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     constexpr bool kAccInit = C::SPLIT || C::LOGTW >= 3;
     // acc = acc * macc + (bias + temb + residual) * inv.  At the start (acc = 0, FIRST): the init; SPLIT tiles whose scale 2^S
     // could overflow the product (asc.late) run it at the end instead with macc = 2^-S, inv = 1.
+    // SPLIT (float32 results): bias + temb do NOT ride in the accumulators -- they are added by the epilogue's own FMA
+    // (out = acc 2^-S + bias: one rounding, no extra instruction).  In the accumulators a bias that dwarfs the products (conv_in
+    // on a 1e-4-scale input: bias 0.1) is re-rounded at ITS ulp by every one of the 3 x 18 MFMAs of a chunk where F.conv2d adds it
+    // once -- harmless relative to the output scale, but a following GroupNorm divides by the SIGNAL's sigma (VERDICT r03 weak #2:
+    // the whole-forward error at input scale 1e-4).  The residual keeps entering through the init: it is a tensor at the output's
+    // own scale, and its loads hide under the first chunk's staging.
+#ifdef CDX_TUNING
+    const bool bias_late = C::SPLIT && !(p.abl & 2048);      // (tuning build, abl 2048: round 3's form, for the before / after record)
+#else
+    constexpr bool bias_late = C::SPLIT != 0;
+#endif
     auto add_terms = [&](auto first_, float macc, float inv) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_)::value;
         const int n = ntile * 32 + li;
         if (!(nvalid && n < p.Cout)) return;
-        float add = p.bias ? p.bias[n] : 0.f;
-        if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
-        add *= inv;
+        float add = 0.f;
+        if (!bias_late) {
+            add = p.bias ? p.bias[n] : 0.f;
+            if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
+            add *= inv;
+        } else if (!p.residual) {
+            return;                                          // nothing to add here: the accumulators stay as they are
+        }
         if (p.residual && !(C::ABL & 16)) {
             // rows past the image end / columns past the row end read other (or no: bounded resource) pixels; those
             // accumulators are never stored
@@ -584,7 +633,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                 }
             }
         }
-        __syncthreads();
+        timed_barrier();
         if (chunk < 8) stamp(3 + chunk);
         if constexpr (!C::DB) {      // single image: every wave is done reading it; write the next chunk in place
             if (more) {
@@ -625,9 +674,14 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         const __amdgpu_buffer_rsrc_t ors = buf_rsrc(static_cast<float*>(p.out) + (first < total ? first : 0), left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)left);
         const unsigned vbase = nok ? ((unsigned)(4 * lh) * os * (unsigned)p.out_ld + (unsigned)n) * 4u : kDrop;
         float un = asc.un;
-        if (asc.late) {                              // (rare: see ActScale) outputs first, then the additive terms at their own scale
+        if (asc.late && (p.residual || !bias_late)) {   // (rare: see ActScale) outputs first, then the additive terms at their own scale
             add_terms(std::false_type{}, un, 1.f);   // (lanes without an output channel keep raw accumulators: never stored)
             un = 1.f;
+        }
+        float addv = 0.f;                            // bias + temb of this lane's channel, added by the store loop's FMA
+        if (bias_late && nok) {
+            addv = p.bias ? p.bias[n] : 0.f;
+            if (p.temb) addv += p.temb[(size_t)b * p.temb_ld + n];
         }
         // (the sums variant also serves amax_out: a caller that wants only one of them pays for both)
         const bool want_stats = (p.stats || p.amax_out) && !(C::ABL & 32);
@@ -641,7 +695,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                     const int mb = t * 32 + 8 * (r >> 2) + (r & 3);
                     const int row = mb >> C::LOGTW, col = mb & (C::TW - 1);
                     const unsigned soff = ((unsigned)row * os * WoutF + (unsigned)col * os) * (unsigned)p.out_ld * 4u;
-                    const float x = acc[t][r] * un;
+                    const float x = fmaf(acc[t][r], un, addv);
                     bool ok = true;
                     if constexpr (!decltype(full_)::value) ok = oy0w + row < p.Hout && ox0 + col + 4 * lh < p.Wout;
                     if constexpr (decltype(has_stats)::value) {
@@ -659,6 +713,9 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         if (full) { if (want_stats) direct(T_{}, T_{}); else direct(T_{}, F_{}); }
         else      { if (want_stats) direct(F_{}, T_{}); else direct(F_{}, F_{}); }
         stamp(12);
+        if constexpr (C::WS && (C::ABL & 512) != 0) {
+            if (lane == 0) reinterpret_cast<unsigned long long*>(p.stats)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 16 + 15] = bar_ticks;
+        }
         if (p.stats && !(C::ABL & 32)) {
             s1 += __shfl_xor(s1, 32);                  // the two lane halves hold different pixels of the same channel
             s2 += __shfl_xor(s2, 32);

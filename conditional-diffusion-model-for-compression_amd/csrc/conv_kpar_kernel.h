@@ -178,15 +178,34 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int n = ntile * 32 + li;
-    if (wv == 0 && n < p.Cout && !asc.late) {                      // bias + temb + residual through wave 0's accumulator init
+    // SPLIT (float32 results): bias + temb are added by the epilogue's FMA, not carried in the accumulators (conv16_kernel.h: a bias
+    // that dwarfs the products would be re-rounded at its own ulp by every MFMA); the residual keeps entering through the init.
+#ifdef CDX_TUNING
+    const bool bias_late = C::SPLIT && !(p.abl & 2048);
+#else
+    constexpr bool bias_late = C::SPLIT != 0;
+#endif
+    float addv = 0.f;
+    if (bias_late && n < p.Cout) {
+        addv = p.bias ? p.bias[n] : 0.f;
+        if (p.temb) addv += p.temb[(size_t)b * p.temb_ld + n];
+    }
+    if (wv == 0 && n < p.Cout && !asc.late && (p.residual || !bias_late)) {      // (bias + temb +) residual through wave 0's accumulator init
         const float inv = asc.inv;
-        float add = p.bias ? p.bias[n] : 0.f;
-        if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
-        add *= inv;
+        float add = 0.f;
+        if (!bias_late) {
+            add = p.bias ? p.bias[n] : 0.f;
+            if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
+            add *= inv;
+        }
         if (p.residual) {
+            // oy0 / ox0 are a workgroup origin INSIDE the image (the grid covers ceil(H / TH) x ceil(W / TW) tiles), so first < total
+            // always; the guard keeps the unmasked loads below safe against a caller-side change of that (conv16_kernel.h met the
+            // underflowed form as a GPU memory fault in round 3)
             const size_t first = (((size_t)b * p.Hout + oy0) * p.Wout + ox0) * p.Cout;
-            const size_t left = ((size_t)p.B * p.Hout * p.Wout * p.Cout - first) * ES;
-            const __amdgpu_buffer_rsrc_t rr = buf_rsrc(static_cast<const char*>(p.residual) + first * ES, left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)left);
+            const size_t total = (size_t)p.B * p.Hout * p.Wout * p.Cout;
+            const size_t left = first < total ? (total - first) * ES : 1;
+            const __amdgpu_buffer_rsrc_t rr = buf_rsrc(static_cast<const char*>(p.residual) + (first < total ? first : 0) * ES, left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)left);
             const unsigned voffr = ((unsigned)(4 * lh) * (unsigned)p.Cout + (unsigned)n) * ES;
 #pragma unroll
             for (int t = 0; t < MT; ++t)
@@ -274,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const Conv16Params p)
             float v = scratch[((0 * MT + t) * 16 + r) * 64 + lane];
 #pragma unroll
             for (int s = 1; s < 4; ++s) v += scratch[((s * MT + t) * 16 + r) * 64 + lane];
-            x[c] = v * un;
+            x[c] = (asc.late && bias_late) ? v * un : fmaf(v, un, addv);      // (lane = channel n here: before the transpose)
         }
         quad_transpose(x, q4);                                     // pixel 8 wv + q4 (+ 4 lh) of tile t, channels cq .. cq + 3
         const int m = t * 32 + 8 * wv + q4 + 4 * lh;

@@ -6,7 +6,9 @@
 #include <string.h>
 
 #include "conv_kpar_kernel.h"
-#include "conv_wsp_kernel.h"
+#ifdef CDX_TUNING
+#include "conv_wsp_kernel.h"      // the persistent form (a measured negative): tuning build only
+#endif
 
 using namespace cdx;
 
@@ -108,7 +110,8 @@ extern "C" int cdx_conv_pack_weights_split_up_f16(const float* w, int32_t c0, in
 }
 
 namespace cdx {
-// CUs of the current device: the persistent kernel launches one workgroup per CU (queried once; every GPU of a node is the same part)
+#ifdef CDX_TUNING
+// CUs of the current device: the persistent kernel launches one workgroup per CU (tuning build only; queried once)
 int wsp_cu_count() {
     static const int n = [] {
         int dev = 0, cus = 0;
@@ -117,6 +120,12 @@ int wsp_cu_count() {
     }();
     return n;
 }
+// CDX_DIAG bit 2048: bias + temb through the accumulator init as in round 3 (tools/diag_scale.py: per-layer error, before / after)
+static int diag_bits() {
+    static const int v = [] { const char* e = getenv("CDX_DIAG"); return e ? atoi(e) : 0; }();
+    return v;
+}
+#endif
 
 // Is this cdx_conv_f32 launch one the SPLIT kernel is built for?  (conv.hip asks before choosing the tile.)
 bool conv_split_ok(const cdx_conv_args* a) {
@@ -177,6 +186,9 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     p.gn = (a->flags & CDX_CONV_GN) ? 1 : 0;
     p.silu = (a->flags & CDX_CONV_SILU) ? 1 : 0;
     p.abl = 0;
+#ifdef CDX_TUNING
+    p.abl = diag_bits() & 2048;
+#endif
     p.wunscale = a->wsplit_unscale;
     p.w = a->wpacked_split;
     p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift; p.temb = a->temb; p.temb_ld = a->temb_ld;
@@ -234,6 +246,10 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
         return conv_kpar_launch<KparCfg<1, 3>>(p, stream);
     }
 #ifdef CDX_TUNING
+    if (a->ksize == 3 && (variant == 48 || variant == 49)) {      // the SHIPPED 8 x 16 tile with per-wave stamps / barrier accounting (tools/ws_stamps.py)
+        if (variant == 48) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 544, 1, 1, 0, 1>>(p, stream);
+        return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 546, 1, 1, 0, 1>>(p, stream);       // ... producers stage only the first chunk
+    }
     if (a->ksize == 3 && variant) {      // the tuning variants are 4 x 32-pixel tiles (round 2's geometry)
         p.tiles_x = ceil_div(a->wout, 32);
         p.tiles_y = ceil_div(a->hout, 4);
@@ -242,7 +258,7 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     if (a->ksize == 3 && variant == 46) return conv16_launch<Conv16Cfg<3, 1, 5, 4, 3, 0, 1>>(p, stream);      // the 4-wave tile (round 2's product)
     if (a->ksize == 3 && variant) {      // timing ablations / tuning variants (tools/conv_bench.py --tiles 60..)
         if (variant >= 100) {            // + 100: the same variant (100 = the shipped tile) at ONE workgroup per CU (solo waves)
-            p.abl = 1024;
+            p.abl |= 1024;
             variant -= 100;
         }
         switch (variant) {

@@ -7,9 +7,11 @@
 //   gn_partial : grid (nsplit, batch); each workgroup sums x and x^2 per channel over its pixel
 //                range, float4 loads, float64 accumulators -> partial[b][split][c][2]
 //   gn_finalize: one wave per (batch, group): sums the partials in float64, mean / rstd, then
-//                scale = rstd*gamma, shift = beta - mean*scale in float32 (F.group_norm's own form).
+//                scale = rstd*gamma in float32 (F.group_norm's own form) and shift = beta - mean*scale evaluated in
+//                float64 and rounded once (gn_affine below).
 // No reference file exists to cite (reference snapshot is empty); semantics = torch F.group_norm.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -22,6 +24,18 @@ constexpr int kPixelsPerSplit = 256;
 __host__ __device__ inline int gn_nsplit(int hw) {
     int n = hw / kPixelsPerSplit;
     return n < 1 ? 1 : (n > 1024 ? 1024 : n);
+}
+
+// scale = rstd * gamma in float32 (times 2^out_exp: exact).  shift = beta - mean * scale is evaluated in FLOAT64 from the float64
+// mean and the FLOAT32 scale the consumer multiplies by, and rounded once: x * scale + shift then equals (x - mean) * scale + beta
+// up to that one rounding.  The all-float32 form rounds the mean, the product and the sum -- each costs |mean| / sigma ulps of the
+// NORMALISED value (a layer whose input is a large constant plus a small signal: conv_in's bias 0.1 + a 1e-4 input is 2000
+// sigmas from zero), which round 3 measured as the whole-forward error at input scale 1e-4.
+// legacy (tuning build only): the round-3 float32 form, for the before / after record.
+__device__ __forceinline__ void gn_affine(double mean, float rstdf, float gamma, float beta, float oscale, bool legacy, float& scale, float& shift) {
+    const float sc = rstdf * gamma;
+    scale = sc * oscale;
+    shift = legacy ? (-sc * (float)mean + beta) * oscale : (float)((double)beta - mean * (double)sc) * oscale;
 }
 
 __global__ __launch_bounds__(256) void gn_partial(const float* __restrict__ src, int C, int hw, int nsplit,
@@ -79,7 +93,7 @@ __global__ __launch_bounds__(64) void gn_finalize(const double* __restrict__ par
                                                   int hw, float eps, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, float* __restrict__ scale,
                                                   float* __restrict__ shift, float* __restrict__ mean_out,
-                                                  float* __restrict__ rstd_out, float oscale) {
+                                                  float* __restrict__ rstd_out, float oscale, bool legacy) {
     const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int cpg = ctot / groups;
     const int items = nsplit * cpg;
@@ -107,9 +121,7 @@ __global__ __launch_bounds__(64) void gn_finalize(const double* __restrict__ par
     }
     for (int k = lane; k < cpg; k += 64) {
         const int c = g * cpg + k;
-        const float sc = rstdf * gamma[c];
-        scale[(size_t)b * ctot + c] = sc * oscale;                       // (oscale = 2^out_exp: exact)
-        shift[(size_t)b * ctot + c] = (-sc * meanf + beta[c]) * oscale;
+        gn_affine(mean, rstdf, gamma[c], beta[c], oscale, legacy, scale[(size_t)b * ctot + c], shift[(size_t)b * ctot + c]);
     }
 }
 
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(256) void gn_finalize2(const double* __restrict__ p
                                                     int hw, float eps, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, float* __restrict__ scale,
                                                     float* __restrict__ shift, float* __restrict__ mean_out,
-                                                    float* __restrict__ rstd_out, float oscale) {
+                                                    float* __restrict__ rstd_out, float oscale, bool legacy) {
     __shared__ double red[2][256];
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int ctot = c0 + c1, cpg = ctot / groups;
@@ -168,11 +180,19 @@ __global__ __launch_bounds__(256) void gn_finalize2(const double* __restrict__ p
     }
     for (int k = tid; k < cpg; k += 256) {
         const int c = cbeg + k;
-        const float sc = rstdf * gamma[c];
-        scale[(size_t)b * ctot + c] = sc * oscale;                       // (oscale = 2^out_exp: exact)
-        shift[(size_t)b * ctot + c] = (-sc * meanf + beta[c]) * oscale;
+        gn_affine(mean, rstdf, gamma[c], beta[c], oscale, legacy, scale[(size_t)b * ctot + c], shift[(size_t)b * ctot + c]);
     }
 }
+
+#ifdef CDX_TUNING
+// tuning build: CDX_DIAG bit 4096 restores the round-3 float32 shift (tools/diag_scale.py: per-layer error, before / after)
+inline bool gn_legacy() {
+    static const bool on = [] { const char* e = getenv("CDX_DIAG"); return e && (atoi(e) & 4096); }();
+    return on;
+}
+#else
+constexpr bool gn_legacy() { return false; }
+#endif
 
 }  // namespace
 
@@ -187,7 +207,7 @@ extern "C" int cdx_gn_finalize_f32(const cdx_gn_finalize_args* a, void*, size_t,
     CDX_REQUIRE(a->out_exp >= -60 && a->out_exp <= 60);
     hipLaunchKernelGGL(gn_finalize2, dim3(a->groups, a->batch), dim3(256), 0, static_cast<hipStream_t>(stream), a->part0,
                        a->slots0, a->c0, a->part1, a->slots1, a->c1, a->groups, a->hw, a->eps, a->gamma, a->beta, a->scale,
-                       a->shift, a->mean, a->rstd, ldexpf(1.f, a->out_exp));
+                       a->shift, a->mean, a->rstd, ldexpf(1.f, a->out_exp), gn_legacy());
     return check_launch();
 }
 
@@ -218,6 +238,6 @@ extern "C" int cdx_gn_stats_f32(const cdx_gn_stats_args* a, void* ws, size_t ws_
         if ((rc = check_launch())) return rc;
     }
     hipLaunchKernelGGL(gn_finalize, dim3(a->groups, a->batch), dim3(64), 0, st, part, nsplit, ctot, a->groups, a->hw,
-                       a->eps, a->gamma, a->beta, a->scale, a->shift, a->mean, a->rstd, ldexpf(1.f, a->out_exp));
+                       a->eps, a->gamma, a->beta, a->scale, a->shift, a->mean, a->rstd, ldexpf(1.f, a->out_exp), gn_legacy());
     return check_launch();
 }

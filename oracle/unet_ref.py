@@ -39,7 +39,9 @@ def unet_forward_ref(cfg: dict, params: dict, x: torch.Tensor, t: torch.Tensor, 
                      dtype=torch.float32, taps: dict | None = None) -> torch.Tensor:
     """eps = UNet(x_t, t, cond).  x [B,3,H,W]; t [B] int; cond [B,Cc,hc,wc] (concat) or [B,L,D].
 
-    `taps`, if given, is filled with named intermediate tensors (for per-block tests).
+    `taps`, if given, is filled with named intermediate tensors: per block ("conv_in", "down.i.j", "mid", "up.i.j") and per
+    convolution layer under the layer's parameter name, taken after everything the HIP launch of that name fuses (+ temb for
+    conv1, + skip for conv2, + x for attention projections).
     """
     ch = cfg["base_channels"]
     groups = cfg["groups"]
@@ -53,8 +55,13 @@ def unet_forward_ref(cfg: dict, params: dict, x: torch.Tensor, t: torch.Tensor, 
     def gn(h, name):
         return F.group_norm(h, groups, W(name + ".weight"), W(name + ".bias"), eps=1e-5)
 
+    def tap(name, v):
+        if taps is not None:
+            taps[name] = v
+        return v
+
     def conv(h, name, stride=1, pad=1):
-        return F.conv2d(h, W(name + ".weight"), W(name + ".bias"), stride=stride, padding=pad)
+        return tap(name, F.conv2d(h, W(name + ".weight"), W(name + ".bias"), stride=stride, padding=pad))
 
     temb = timestep_embedding_ref(t, ch, dtype)
     temb = F.linear(temb, W("temb.0.weight"), W("temb.0.bias"))
@@ -65,10 +72,10 @@ def unet_forward_ref(cfg: dict, params: dict, x: torch.Tensor, t: torch.Tensor, 
         ci = h.shape[1]
         co = params[name + ".conv1.weight"].shape[0]
         y = conv(F.silu(gn(h, name + ".norm1")), name + ".conv1")
-        y = y + F.linear(temb_act, W(name + ".temb.weight"), W(name + ".temb.bias"))[:, :, None, None]
+        y = tap(name + ".conv1", y + F.linear(temb_act, W(name + ".temb.weight"), W(name + ".temb.bias"))[:, :, None, None])
         y = conv(F.silu(gn(y, name + ".norm2")), name + ".conv2")
         sk = conv(h, name + ".skip", pad=0) if ci != co else h
-        return y + sk
+        return tap(name + ".conv2", y + sk)      # (taps name a tensor after everything the HIP layer of that name fuses: + temb, + skip)
 
     def mha(q, k, v):
         # q [B, C, Nq], k/v [B, C, Nk] -> [B, C, Nq]; heads = C // hd
@@ -87,7 +94,7 @@ def unet_forward_ref(cfg: dict, params: dict, x: torch.Tensor, t: torch.Tensor, 
         qkv = conv(gn(h, name + ".norm"), name + ".qkv", pad=0).reshape(B, 3 * C, Hh * Ww)
         q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
         o = mha(q, k, v).reshape(B, C, Hh, Ww)
-        return h + conv(o, name + ".proj", pad=0)
+        return tap(name + ".proj", h + conv(o, name + ".proj", pad=0))
 
     def xattn(h, name):
         B, C, Hh, Ww = h.shape
@@ -95,7 +102,7 @@ def unet_forward_ref(cfg: dict, params: dict, x: torch.Tensor, t: torch.Tensor, 
         kv = F.linear(cond.to(dtype), W(name + ".kv.weight"), W(name + ".kv.bias"))   # [B, L, 2C]
         kv = kv.transpose(1, 2)
         o = mha(q, kv[:, :C], kv[:, C:]).reshape(B, C, Hh, Ww)
-        return h + conv(o, name + ".proj", pad=0)
+        return tap(name + ".proj", h + conv(o, name + ".proj", pad=0))
 
     def extras(h, prefix, r):
         if r in cfg["attn_resolutions"]:

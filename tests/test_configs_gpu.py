@@ -8,7 +8,7 @@ configs[4]: 1024x1024x3 decoded as 25 overlapping 256^2 tiles (overlap 64) throu
             steps: finite, clamped, equal to the per-tile decodes blended by the oracle's float64 blend, exact in tile
             cores, and within the stated fp16 tolerance of the float32 HIP decode of the same image.
 
-Tolerances: float32 as in test_e2e_gpu.py (forward <= 2e-5 x scale vs float64; PSNR(hip, oracle) >= 80 dB;
+Tolerances: float32 as in test_e2e_gpu.py (forward <= 6e-6 x scale vs float64 (8e-6 vs the float32 oracle at full size); PSNR(hip, oracle) >= 80 dB;
 |dPSNR vs target| <= 0.01 dB); fp16 as in test_fp16_gpu.py (PSNR >= 45 dB, |dPSNR| <= 0.01 dB).
 """
 import math
@@ -56,7 +56,7 @@ def test_cfg4_widths_reduced_image_forward_and_ddpm(cdx_mod, record):
     got = net.forward(x.cuda(), t.cuda(), cond.cuda()).cpu()
     err, scale = (got.double() - want).abs().max().item(), want.abs().max().item()
     record("cfg4_128_forward", hip_vs_fp64=err, scale=scale)
-    assert err <= 2e-5 * max(1.0, scale), f"max err {err:.3e} (scale {scale:.3e})"
+    assert err <= 6e-6 * max(1.0, scale), f"max err {err:.3e} (scale {scale:.3e})"      # (measured 2.6e-6: twice that)
     # sampler: the benchmark's weights (out_gain 0.05), DDPM noise every step
     params = cdx_mod.init_params(cfg, seed=4)
     tgt = torch.from_numpy(sb["target"])
@@ -83,7 +83,7 @@ def test_cfg4_full_size_vs_live_oracle(cdx_mod, record):
     got = cdx_mod.UNet(cfg, params).forward(x.cuda(), t.cuda(), cond.cuda()).cpu()
     err, scale = (got.double() - want.double()).abs().max().item(), want.abs().max().item()
     record("cfg4_full_forward", hip_vs_cpu_fp32=err, scale=scale)
-    assert err <= 2e-5 * max(1.0, scale), f"max err {err:.3e} (scale {scale:.3e})"
+    assert err <= 8e-6 * max(1.0, scale), f"max err {err:.3e} (scale {scale:.3e})"      # (measured 3.1-4.1e-6 against the FLOAT32 oracle, which is itself ~1e-6 off: twice that)
     del want, got
     torch.cuda.empty_cache()
     params = cdx_mod.init_params(cfg, seed=0)

@@ -73,7 +73,8 @@ def test_unet_forward_matches_oracle(cdx_mod, record, name, over, split):
     cpu32 = oracle.unet_forward_ref(cfg, params, x, t, cond)
     record("unet_forward_" + name, hip_vs_fp64=err, cpu_fp32_vs_fp64=(cpu32.double() - want).abs().max().item(),
            scale=want.abs().max().item())
-    assert err <= 2e-5 * max(1.0, want.abs().max().item()), f"{name}: max err {err:.3e}"
+    # (measured 1.4-3.1e-6 x scale, the CPU float32 oracle 1.2-2.4e-6: profiles/r03_z_parity_metrics.jsonl; the gate is 2x the worst)
+    assert err <= 6e-6 * max(1.0, want.abs().max().item()), f"{name}: max err {err:.3e}"
 
 
 def test_cross_attention_unet_matches_oracle(cdx_mod, record):
@@ -89,7 +90,7 @@ def test_cross_attention_unet_matches_oracle(cdx_mod, record):
     got = cdx_mod.UNet(cfg, params).forward(x.cuda(), t.cuda(), cond.cuda()).cpu()
     err = (got.double() - want).abs().max().item()
     record("unet_forward_xattn", hip_vs_fp64=err, scale=want.abs().max().item())
-    assert err <= 2e-5 * max(1.0, want.abs().max().item()), f"max err {err:.3e}"
+    assert err <= 6e-6 * max(1.0, want.abs().max().item()), f"max err {err:.3e}"
 
 
 def test_sampler_cfg1_golden(cdx_mod, record):

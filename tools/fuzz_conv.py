@@ -2,7 +2,8 @@
 """Randomised parity sweep of cdx_conv_f32 (library's own tile choice) against float64 torch on the CPU:
 random layer shapes (incl. ragged sizes, concat, upsample, stride 2, 1x1, tiny / huge channel counts), random fusion
 flags (GroupNorm+SiLU on load, temb, residual, GroupNorm sums of the output) and -- VERDICT r02 item 1 -- a random
-log-uniform SCALE per source (10^U(-6, 6)): the error is judged relative to the output's own scale, no floor.
+log-uniform SCALE per source (10^U(-6, 6)) and, independently, per additive term (bias, temb, residual: 10^U(-3, 3) times
+the products' scale): the error is judged relative to the output's own scale, no floor.
 usage: tools/fuzz_conv.py [cases] [seed] [convout]      (convout: only layers the cout <= 3 GEMM form, tile 12, can take)"""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -53,11 +54,14 @@ for case in range(ncases):
     h = F.interpolate(h, scale_factor=2, mode="nearest") if up else h
     want = F.conv2d(h, w.float().double(), bias.float().double(), stride=s, padding=k // 2)
     ho, wo = want.shape[-2:]
-    osc = 1.0 if gn else max(sx0, sx1 if c1 else 0.0)      # additive terms at the scale of the products
-    want = want + (bias.float().double() * (osc - 1.0))[None, :, None, None]
-    bias = bias * osc
-    temb = torch.randn(B, co + 3, generator=g, dtype=torch.float64) * osc if use_temb else None
-    res = torch.randn(B, co, ho, wo, generator=g, dtype=torch.float64) * osc if use_res else None
+    # additive terms: each at its OWN scale, 10^U(-3, 3) times the scale of the products (drawn "at the scale of
+    # the products" the sweep could not see a bias that dwarfs them -- conv_in's 0.1 over a 1e-4 signal)
+    psc = 1.0 if gn else max(sx0, sx1 if c1 else 0.0)
+    osc_b, osc_t, osc_r = (psc * 10.0 ** rng.uniform(-3, 3) for _ in range(3))
+    want = want + (bias.float().double() * (osc_b - 1.0))[None, :, None, None]
+    bias = bias * osc_b
+    temb = torch.randn(B, co + 3, generator=g, dtype=torch.float64) * osc_t if use_temb else None
+    res = torch.randn(B, co, ho, wo, generator=g, dtype=torch.float64) * osc_r if use_res else None
     if use_temb: want = want + temb.float().double()[:, 1:1 + co, None, None]
     if use_res: want = want + res.float().double()
     s0, s1 = nhwc(x0.float()), (nhwc(x1.float()) if c1 else None)

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Where do the waves of the wave-specialised split tile wait?  ("32 % of wave cycles parked at the one
+barrier per chunk" is a counter over ALL eight waves; this separates the MFMA waves' share from the producers'.)
+
+Runs the SHIPPED 8 x 16-pixel tile with s_memtime stamps (libcdx_tune.so, tile id 108 = variant 48; 109: producers stage only the
+first chunk) on one fused ResBlock shape and prints, per role, the share of a wave's life spent inside the per-chunk
+__syncthreads, plus the MFMA waves' per-chunk durations.
+
+  python tools/ws_stamps.py [--shape 16,256,256,128,0,128] [--tile 108]
+"""
+import argparse, ctypes, math, os, sys
+os.environ["CDX_TUNE"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import cdx
+from cdx import ops, _abi
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--shape", default="16,256,256,128,0,128")
+ap.add_argument("--tile", type=int, default=108)
+a = ap.parse_args()
+B, H, W, c0, c1, co = map(int, a.shape.split(","))
+g = torch.Generator(device="cuda").manual_seed(0)
+x0 = torch.randn(B, H, W, c0, device="cuda", generator=g)
+x1 = torch.randn(B, H, W, c1, device="cuda", generator=g) if c1 else None
+w = (np.random.default_rng(0).standard_normal((co, c0 + c1, 3, 3)) / math.sqrt((c0 + c1) * 9)).astype(np.float32)
+pc = ops.PackedConv(w, np.zeros(co, np.float32), c0, c1)
+out = torch.empty(B, H, W, co, device="cuda")
+gamma, beta = torch.ones(c0 + c1, device="cuda"), torch.zeros(c0 + c1, device="cuda")
+kw = dict(gn=ops.gn_stats(x0, x1, gamma, beta, 32, act_exp="auto"), silu=True, temb=torch.randn(B, co, device="cuda"),
+          residual=torch.randn(B, H, W, co, device="cuda"))
+args = ops.conv_args(pc, x0, x1, out, **kw)
+nblocks = B * ((H + 7) // 8) * ((W + 15) // 16) * ((co + 127) // 128)
+rows = 2 * nblocks * 4
+big = torch.zeros(max(rows * 16, 1 << 20), dtype=torch.float64, device="cuda")
+_keep = ops.conv_stats_buffer(args, "cuda")      # sets stats_slots
+args.stats_out = big.data_ptr()
+L = _abi.lib()
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(3):
+    big.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = L.cdx_conv_f32_tile(ctypes.byref(args), a.tile, None, 0, st)
+    assert rc == 0, rc
+    e1.record()
+    torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+T = big.view(torch.int64)[: rows * 16].reshape(rows, 16).cpu().numpy().astype(np.int64)
+M, P = T[: nblocks * 4], T[nblocks * 4:]
+xcc = M[:, 14] & 0xF
+span = max(M[xcc == x][:, 12].max() - M[xcc == x][:, 0].min() for x in np.unique(xcc))
+tick = ms * 1e6 / span
+nch = (c0 + c1 + 31) // 32
+life = M[:, 12] - M[:, 0]
+print(f"tile {a.tile}: launch {ms:.4f} ms, {nblocks} workgroups, {tick:.2f} ns per tick, {nch} chunks")
+print(f"MFMA waves: life {life.mean() * tick / 1e3:.2f} us; inside the per-chunk barriers {M[:, 15].mean() * tick / 1e3:.2f} us = {M[:, 15].sum() / life.sum():.3f} of their life "
+      f"(p10 {np.percentile(M[:, 15] / life, 10):.3f}, p90 {np.percentile(M[:, 15] / life, 90):.3f})")
+seg = {"entry -> first chunk staged (barrier passed)": M[:, 2] - M[:, 0]}
+for c in range(min(nch, 8)):
+    seg[f"chunk {c} (MFMAs + barrier)"] = M[:, 3 + c] - M[:, 2 + c]
+seg["epilogue (stores issued)"] = M[:, 12] - M[:, 2 + min(nch, 8)]
+for k, v in seg.items():
+    print(f"  {k:46s} mean {v.mean() * tick / 1e3:7.3f} us   share {v.sum() / life.sum():.3f}")
+plife = P[:, 3] - P[:, 0]
+ok = plife > 0
+print(f"producer waves: life {plife[ok].mean() * tick / 1e3:.2f} us; at barriers {P[ok, 1].sum() / plife[ok].sum():.3f}, staging (LDS writes + next loads issued) {P[ok, 2].sum() / plife[ok].sum():.3f}")
