@@ -13,8 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/conv_bench.py only); the product always loads libcdx.so.
 LIB_PATH = os.path.join(_HERE, "libcdx_tune.so" if os.environ.get("CDX_TUNE") == "1" else "libcdx.so")
 
-ABI_VERSION = 4
-CONV_UPSAMPLE2X, CONV_GN, CONV_SILU, CONV_BF16 = 1, 2, 4, 8
+ABI_VERSION = 5
+CONV_UPSAMPLE2X, CONV_GN, CONV_SILU, CONV_BF16, CONV_GN_EXP = 1, 2, 4, 8, 16
 LINEAR_SILU_IN = 1
 CONV_KC = 32
 AMAX_WORDS = 16          # words per image of the amax arrays (cdx.h CDX_AMAX_WORDS)

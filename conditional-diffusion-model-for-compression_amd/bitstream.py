@@ -136,8 +136,5 @@ def decode_bitstreams(sampler, ctx, containers, steps: int, *, out_path: str | N
     if out_path is None:
         return sampler.sample(cond, steps, **kw)
     from .image_io import to_uint8, write_images
-    run = sampler.begin(cond, steps, **kw)
-    for k in range(steps):
-        sampler.step(run, k)
-    write_images(out_path, to_uint8(run.plan.xin, nhwc_channels=run.channels))
-    return sampler.finish(run)
+    # (the ONE sampling loop is Sampler.sample: the files are written from its state buffer through the on_finish hook)
+    return sampler.sample(cond, steps, on_finish=lambda run: write_images(out_path, to_uint8(run.plan.xin, nhwc_channels=run.channels)), **kw)

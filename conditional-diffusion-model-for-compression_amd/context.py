@@ -125,8 +125,9 @@ class _CtxPlan:
             a = ops.conv_args(pc, src, None, out, upsample=upsample, gn=gnp, silu=norm is not None, residual=residual, out_ld=out_ld)
             if split and norm is not None:
                 a.gn_exp = _abi.gn_act_exp(net.host[norm + ".weight"], net.host[norm + ".bias"], g, h * w)
+                a.flags |= _abi.CONV_GN_EXP
                 if _abi.lib().cdx_conv_select_tile(ctypes.byref(a)) != _abi.TILE_SPLIT:
-                    a.gn_exp = 0
+                    a.gn_exp, a.flags = 0, a.flags & ~_abi.CONV_GN_EXP
             elif split:
                 a.src_amax0 = amax_of(src).data_ptr()
                 if _abi.lib().cdx_conv_select_tile(ctypes.byref(a)) == _abi.TILE_SPLIT:

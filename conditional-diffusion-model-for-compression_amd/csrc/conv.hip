@@ -185,7 +185,8 @@ int validate(const cdx_conv_args* a) {
     CDX_REQUIRE((a->c1 == 0) == (a->src1 == nullptr));
     if (a->c1) CDX_REQUIRE((a->c0 % CDX_CONV_KC) == 0 && (a->c1 % CDX_CONV_KC) == 0);
     CDX_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->cout > 0);
-    CDX_REQUIRE((a->flags & ~(CDX_CONV_UPSAMPLE2X | CDX_CONV_GN | CDX_CONV_SILU)) == 0);   // unknown flag bits are an error (CDX_CONV_BF16: cdx_conv_f16 only)
+    CDX_REQUIRE((a->flags & ~(CDX_CONV_UPSAMPLE2X | CDX_CONV_GN | CDX_CONV_SILU | CDX_CONV_GN_EXP)) == 0);   // unknown flag bits are an error (CDX_CONV_BF16: cdx_conv_f16 only)
+    if (a->flags & CDX_CONV_GN_EXP) CDX_REQUIRE(a->flags & CDX_CONV_GN);
     CDX_REQUIRE(a->ksize == 1 || a->ksize == 3);
     CDX_REQUIRE(a->stride == 1 || (a->stride == 2 && a->ksize == 3));
     const int ups = (a->flags & CDX_CONV_UPSAMPLE2X) ? 1 : 0;
@@ -198,7 +199,7 @@ int validate(const cdx_conv_args* a) {
     if (a->wpacked_split) CDX_REQUIRE(aligned16(a->wpacked_split) && a->wsplit_unscale > 0.f);
     if (a->wpacked_split_up) CDX_REQUIRE(aligned16(a->wpacked_split_up) && a->wpacked_split != nullptr);
     CDX_REQUIRE(a->gn_exp >= -60 && a->gn_exp <= 60);
-    if (!(a->flags & CDX_CONV_GN)) CDX_REQUIRE(a->gn_exp == 0);
+    if (!(a->flags & CDX_CONV_GN_EXP)) CDX_REQUIRE(a->gn_exp == 0);
     if (a->amax_out) CDX_REQUIRE((a->cout % 4) == 0 && (a->out_ld % 4) == 0 && aligned16(a->out));
     CDX_REQUIRE(((reinterpret_cast<uintptr_t>(a->src_amax0) | reinterpret_cast<uintptr_t>(a->src_amax1) | reinterpret_cast<uintptr_t>(a->amax_out)) & 63u) == 0);
     if (a->temb) CDX_REQUIRE(a->temb_ld >= a->cout);
@@ -295,7 +296,7 @@ extern "C" int cdx_conv_f32_tile(const cdx_conv_args* a, int32_t tile, void*, si
     if (t.wcfg == WCFG_SPLIT) return conv_split_launch(a, st);      // (scales its activations by 2^gn_exp / amax; writes amax_out)
     // the f32-input MFMA kernels take GroupNorm scale / shift at unit scale: a pre-multiplied pair belongs to the split tile
     // (the host asks cdx_conv_select_tile first and passes out_exp = gn_exp = 0 otherwise)
-    CDX_REQUIRE(a->gn_exp == 0);
+    CDX_REQUIRE(a->gn_exp == 0 && !(a->flags & CDX_CONV_GN_EXP));
     if (t.wcfg == WCFG_WINO || (experimental && tile >= 31)) {
         if (!wino_ok(a)) return CDX_ENOTSUP;
         p.w = a->wpacked_wino;

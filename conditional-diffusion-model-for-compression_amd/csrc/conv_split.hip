@@ -133,6 +133,9 @@ bool conv_split_ok(const cdx_conv_args* a) {
     // RANGE CONTRACT (cdx.h): the staged activations need a power-of-two exponent -- static for GroupNorm-ed inputs (gn_exp),
     // per image from the producers' amax words otherwise.  A launch that brings neither runs on the f32-input MFMA kernels.
     if (!(a->flags & CDX_CONV_GN) && (!a->src_amax0 || (a->c1 > 0 && !a->src_amax1))) return false;
+    // (... and a GroupNorm-ed launch must STATE its exponent: the plain scale / shift pair -- gn_exp 0 by default -- would be staged at
+    // unit scale with no clamp, so a large |gamma| could leave the fp16 range where the f32 tiles are exact: ADVICE r03)
+    if ((a->flags & CDX_CONV_GN) && !(a->flags & CDX_CONV_GN_EXP)) return false;
     // (below 8 pixels wide the f32-MFMA split-K tiles stay)
     if (a->wout < 8 || a->cout <= 4) return false;
     if (a->stride == 2 && a->wout < 16) return false;
@@ -196,7 +199,7 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     p.out = a->out; p.out_f32 = 1; p.out_ld = a->out_ld; p.stats = a->stats_out;
     p.stats_wm = conv_split_slots_per_tile(a);
     p.ostep = 1; p.ody = p.odx = 0; p.pady = p.padx = a->ksize / 2; p.slot_base = 0; p.nslots_total = 0;
-    p.act_exp = (a->flags & CDX_CONV_GN) ? a->gn_exp : 0;
+    p.act_exp = (a->flags & CDX_CONV_GN_EXP) ? a->gn_exp : 0;
     p.amax[0] = (a->flags & CDX_CONV_GN) ? nullptr : a->src_amax0;
     p.amax[1] = (a->flags & CDX_CONV_GN) || a->c1 == 0 ? nullptr : a->src_amax1;
     p.amax_out = a->amax_out;

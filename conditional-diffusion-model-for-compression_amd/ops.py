@@ -165,7 +165,8 @@ def conv_args(pc: PackedConv, src0, src1, out, *, stride=1, upsample=False, gn=N
             a.wsplit_up_unscale[i] = u
     if gn is not None:
         a.gn_scale, a.gn_shift = _ptr(gn[0]), _ptr(gn[1])
-        a.gn_exp = int(gn[2]) if len(gn) > 2 else 0
+        if len(gn) > 2:      # the exponent is STATED (cdx.h CDX_CONV_GN_EXP): only then may the launch take the split tile
+            a.gn_exp, a.flags = int(gn[2]), a.flags | _abi.CONV_GN_EXP
     if src_amax is not None:
         a.src_amax0 = _ptr(src_amax[0])
         a.src_amax1 = _ptr(src_amax[1]) if len(src_amax) > 1 else None

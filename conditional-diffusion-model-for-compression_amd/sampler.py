@@ -47,11 +47,13 @@ class Sampler:
 
     @torch.no_grad()
     def sample(self, cond: torch.Tensor, steps: int, *, seed: int = 0, first_image: int = 0,
-               trace: list | None = None, x_T: torch.Tensor | None = None) -> torch.Tensor:
+               trace: list | None = None, x_T: torch.Tensor | None = None, on_finish=None) -> torch.Tensor:
         """cond [B,Cc,hc,wc] or [B,L,D] -> x_0 [B,C,H,W] in [-1,1] on the UNet's device.
 
         `first_image` is the global index of cond[0] (noise streams are keyed by global index).
         `x_T` [B,C,H,W], if given, replaces the generator's x_T (tiled decode: crops of one noise field).
+        `on_finish(run)`, if given, is called after the last step with the decode's state still in the plan's buffers (e.g. the
+        8-bit export straight from run.plan.xin: bitstream.decode_bitstreams) -- so no caller re-implements this loop.
         = begin() + `steps` x step() + finish(); bench.py times exactly these step() calls.
         """
         run = self.begin(cond, steps, seed=seed, first_image=first_image, x_T=x_T)
@@ -59,6 +61,8 @@ class Sampler:
             self.step(run, k)
             if trace is not None:
                 trace.append(run.plan.xin[..., :run.channels].permute(0, 3, 1, 2).clone())
+        if on_finish is not None:
+            on_finish(run)
         return self.finish(run)
 
     @torch.no_grad()

@@ -115,8 +115,9 @@ class _Plan:
                 # GroupNorm-ed input: static exponent from the affine parameters, if the launch takes the split tile
                 hw = src0.shape[1] * src0.shape[2]
                 a.gn_exp = _abi.gn_act_exp(net.host[norm + ".weight"], net.host[norm + ".bias"], cfg["groups"], hw)
+                a.flags |= _abi.CONV_GN_EXP
                 if _abi.lib().cdx_conv_select_tile(ctypes.byref(a)) != _abi.TILE_SPLIT:
-                    a.gn_exp = 0
+                    a.gn_exp, a.flags = 0, a.flags & ~_abi.CONV_GN_EXP
             elif split:
                 # un-normalised input: per-image maxima from the producers, if the launch takes the split tile with them
                 srcs = [src0] + ([src1] if src1 is not None else [])

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CDX_ABI_VERSION 4
+#define CDX_ABI_VERSION 5
 
 typedef void* cdx_stream_t; /* hipStream_t */
 
@@ -54,7 +54,11 @@ enum {
     CDX_CONV_UPSAMPLE2X = 1, /* sources are nearest-upsampled x2 before the conv (U5) */
     CDX_CONV_GN = 2,         /* apply x*gn_scale[b][c] + gn_shift[b][c] while staging (U2) */
     CDX_CONV_SILU = 4,       /* then x * sigmoid(x) (U2) */
-    CDX_CONV_BF16 = 8        /* cdx_conv_f16 only: the 16-bit tensors and weights are bfloat16 (v_mfma_f32_32x32x16_bf16) */
+    CDX_CONV_BF16 = 8,       /* cdx_conv_f16 only: the 16-bit tensors and weights are bfloat16 (v_mfma_f32_32x32x16_bf16) */
+    CDX_CONV_GN_EXP = 16     /* cdx_conv_f32 with CDX_CONV_GN (ABI v5): gn_exp is STATED -- gn_scale / gn_shift were written with
+                                out_exp = gn_exp = cdx_gn_act_exp(...) of this GroupNorm.  Only such a launch may take the split
+                                tile: a GroupNorm-ed launch that does not state its exponent (the plain scale / shift pair, whose
+                                values could leave the fp16 range for large |gamma|) runs on the f32-input MFMA kernels */
 };
 
 #define CDX_CONV_KC 32 /* input-channel chunk of the packed weight layout */
@@ -93,14 +97,16 @@ typedef struct cdx_conv_args {
                               8 of 64.  RANGE CONTRACT (ABI v4): the activations are staged as x 2^e with a power of two
                               e that places the tensor's maximum in [2^14, 2^15), so the result keeps float32-level
                               error relative to the OUTPUT scale at ANY input scale.  e comes from
-                                * gn_exp       for CDX_CONV_GN launches (static: the normalised tensor's bound), or
+                                * gn_exp       for CDX_CONV_GN | CDX_CONV_GN_EXP launches (static: the normalised tensor's bound), or
                                 * src_amax0/1  for un-normalised launches (per image, from the producing launches);
-                              an un-normalised launch WITHOUT src_amax0 (or without src_amax1 when c1 > 0) never takes
-                              the split tile: it runs on the f32-input MFMA kernels, which need no scaling.
+                              an un-normalised launch WITHOUT src_amax0 (or without src_amax1 when c1 > 0), and a GroupNorm-ed
+                              launch WITHOUT CDX_CONV_GN_EXP, never take the split tile: they run on the f32-input MFMA
+                              kernels, which need no scaling.
                               NaN / +-Inf inputs propagate as in F.conv2d (non-finite outputs over their footprint). */
     float wsplit_unscale;  /* the packer's `unscale` output (2^-s, exact); > 0 whenever wpacked_split is set */
     int32_t gn_exp;        /* CDX_CONV_GN: gn_scale / gn_shift hold scale 2^gn_exp, shift 2^gn_exp (cdx_gn_*_args.out_exp of
-                              the launch that wrote them; |gn_exp| <= 60); the kernels undo it exactly.  0 = plain. */
+                              the launch that wrote them; |gn_exp| <= 60); the kernels undo it exactly.  Read only with
+                              CDX_CONV_GN_EXP (must be 0 without it). */
     const uint32_t* src_amax0; /* NULL, or device [batch][CDX_AMAX_WORDS]: float32 BIT PATTERNS whose maximum is an upper bound
                               of max |x| over image b of src0 -- the `amax_out` words of the launch that produced src0, or
                               cdx_amax_f32's output (64-byte aligned) */

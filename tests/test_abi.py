@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(cdx._abi.EXPORTS), declared ^ set(cdx._abi.EXPORTS)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.cdx_abi_version() == 4
+    assert lib.cdx_abi_version() == 5
     assert b"workspace" in lib.cdx_strerror(-2) and lib.cdx_strerror(0) == b"ok"
 
 

@@ -134,7 +134,10 @@ def test_conv_fused_gn_silu_concat_temb_residual(cdx_mod, B, c0, c1, co, H, W, g
     close(rstd.cpu(), (xg.var(-1, unbiased=False) + 1e-5).rsqrt(), 1e-6, "gn rstd")
     pc = ops.PackedConv(w.numpy(), bias.numpy(), c0, c1)
     for tile in tiles_for(3, 1, W, co, gemm=not c1 and c0 in (64, 128, 192, 256)):
-        got = nchw(ops.conv(pc, s0, s1, gn=(sc, sh), silu=True, temb=temb.cuda(), temb_off=2, residual=nhwc(res), tile=tile))
+        # (the split tile takes a GroupNorm-ed launch only with its exponent STATED -- cdx.h CDX_CONV_GN_EXP: gn_affine computes the
+        # statistics with the exponent the chosen tile wants; the plain pair serves the f32-MFMA tiles)
+        gnkw = dict(gn_affine=(gamma.cuda(), beta.cuda(), groups)) if tile in (-1, 11) else dict(gn=(sc, sh))
+        got = nchw(ops.conv(pc, s0, s1, silu=True, temb=temb.cuda(), temb_off=2, residual=nhwc(res), tile=tile, **gnkw))
         close(got, want, 5e-6 if tile == 7 else 3e-6, f"fused conv tile {tile}")
 
 

@@ -238,6 +238,24 @@ def test_unnormalised_launch_without_amax_falls_back_to_f32_tiles(ops):
     sc, sh = torch.ones(B, ci, device="cuda"), torch.zeros(B, ci, device="cuda")
     a = ops.conv_args(pc, xd, None, out, gn=(sc, sh, 5))
     assert cdx._abi.lib().cdx_conv_f32_tile(ctypes.byref(a), 0, None, 0, None) == -1
+    # ADVICE r03 (ABI v5): a GroupNorm-ed launch that does NOT state its exponent (the plain pair of ops.gn_stats) never takes the
+    # split tile -- unit-scale fp16 staging without a clamp would turn a large |gamma| x_hat into Inf where the f32 tiles are exact
+    a = ops.conv_args(pc, xd, None, out, gn=(sc, sh))
+    assert not (a.flags & cdx._abi.CONV_GN_EXP) and a.gn_exp == 0
+    assert cdx._abi.lib().cdx_conv_select_tile(ctypes.byref(a)) != SPLIT
+    assert cdx._abi.lib().cdx_conv_f32_tile(ctypes.byref(a), SPLIT, None, 0, None) == -4          # CDX_ENOTSUP
+    a.gn_exp = 3                                                                                   # an exponent without the flag: EINVAL
+    assert cdx._abi.lib().cdx_conv_f32_tile(ctypes.byref(a), -1, None, 0, None) == -1
+    a = ops.conv_args(pc, xd, None, out, gn=(sc, sh, 0))                                           # stated (even 0): the split tile
+    assert (a.flags & cdx._abi.CONV_GN_EXP) and cdx._abi.lib().cdx_conv_select_tile(ctypes.byref(a)) == SPLIT
+    gam = torch.full((ci,), 300.0)                  # |gamma| 300: 300 x 4-sigma values are beyond fp16's 65504 at unit scale...
+    xb = rnd(B, ci, H, W, seed=73) ** 3             # (heavy tails: |x_hat| up to ~30)
+    want = F.conv2d(F.group_norm(xb.double(), 32, gam.double(), torch.zeros(ci).double()), w.double(), None, padding=1)
+    xbd = nhwc(xb)
+    plain = nchw(ops.conv(pc, xbd, gn=ops.gn_stats(xbd, None, gam.cuda(), torch.zeros(ci).cuda(), 32)))      # ... so the plain pair runs on f32 tiles
+    stated = nchw(ops.conv(pc, xbd, gn_affine=(gam.cuda(), torch.zeros(ci).cuda(), 32)))                    # ... and the stated form scales it down
+    assert torch.isfinite(plain).all() and torch.isfinite(stated).all()
+    assert rel_err(plain, want) <= 4e-6 and rel_err(stated, want) <= 4e-6
 
 
 def test_sources_beyond_4_gib_index_correctly(ops):
