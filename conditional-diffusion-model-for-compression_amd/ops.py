@@ -284,7 +284,7 @@ def conv(pc: PackedConv, src0, src1=None, **kw):
         ga = gn_stats_args(src0, src1, gamma, beta, groups, sc, sh, out_exp=e)
         wp, wb, keep = _ws(_abi.workspace_bytes("gn_stats_f32", ga), src0.device)
         _call("gn_stats_f32", ga, wp, wb, src0)
-        kw["gn"] = (sc, sh, e)
+        kw["gn"] = (sc, sh, e) if split else (sc, sh)      # (the exponent is STATED only to the tile that undoes it: cdx.h CDX_CONV_GN_EXP)
     if auto_range and kw.get("gn") is None and kw.get("src_amax") is None and pc.w_split is not None:
         kw["src_amax"] = (amax(src0),) + ((amax(src1),) if src1 is not None else ())
     a = conv_args(pc, src0, src1, out, **kw)
