@@ -18,7 +18,7 @@ int validate(const cdx_conv_f16_args* a) {
     if (a->c1) CDX_REQUIRE((a->c0 % 32) == 0 && (a->c1 % 32) == 0);
     CDX_REQUIRE(a->batch > 0 && a->hin > 0 && a->win > 0 && a->cout > 0);
 #ifdef CDX_TUNING
-    CDX_REQUIRE((a->flags & ~(CDX_CONV_UPSAMPLE2X | CDX_CONV_GN | CDX_CONV_SILU | CDX_CONV_BF16 | 0x700)) == 0);
+    CDX_REQUIRE((a->flags & ~(CDX_CONV_UPSAMPLE2X | CDX_CONV_GN | CDX_CONV_SILU | CDX_CONV_BF16 | 0xF00)) == 0);
 #else
     CDX_REQUIRE((a->flags & ~(CDX_CONV_UPSAMPLE2X | CDX_CONV_GN | CDX_CONV_SILU | CDX_CONV_BF16)) == 0);   // unknown flag bits are an error
 #endif
@@ -83,6 +83,7 @@ int conv16_dispatch(int ks, int stride, int logtw, int mt, bool bf, const Conv16
             case 6: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 2, 0, 1, 0, 1>>(p, stream);      // ... producers stage only the first chunk (the MFMA waves' bound)
             case 3: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 1, 0, 1, 0, 1>>(p, stream);      // ... no epilogue
             case 2: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 3, 0, 1, 0, 1>>(p, stream);      // ... neither
+            case 8: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 4096, 0, 1, 0, 1>>(p, stream);   // ... operand reads NOT software-pipelined (round 3's MFMA waves)
             default: return CDX_ENOTSUP;
         }
     }
@@ -178,7 +179,7 @@ extern "C" int cdx_conv_f16(const cdx_conv_f16_args* a, void*, size_t, cdx_strea
     p.ups = (a->flags & CDX_CONV_UPSAMPLE2X) ? 1 : 0;
     p.gn = (a->flags & CDX_CONV_GN) ? 1 : 0;
     p.silu = (a->flags & CDX_CONV_SILU) ? 1 : 0;
-    p.abl = (a->flags >> 8) & 7;
+    p.abl = (a->flags >> 8) & 15;
     p.wunscale = 1.f;
     p.w = a->wpacked;
     p.bias = a->bias; p.gscale = a->gn_scale; p.gshift = a->gn_shift; p.temb = a->temb; p.temb_ld = a->temb_ld;

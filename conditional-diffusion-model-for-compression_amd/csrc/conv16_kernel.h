@@ -212,6 +212,8 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     constexpr int MT = C::MT / WM;                                 // M-tiles PER WAVE
     static_assert(C::MT % WM == 0 && (MT * 32) % C::TW == 0, "a wave's M-tiles must be whole tile rows");
     constexpr int PF = C::PF < GPC ? C::PF : GPC;
+    // software-pipelined operand reads in the MFMA waves (below); ABL 4096 (tuning build): off, for the in-process A/B
+    constexpr bool kPipe = C::WS && GPC > 2 && !(C::ABL & 4096);
 
     const int tid = C::WS ? (int)(threadIdx.x & 255u) : (int)threadIdx.x;      // WS: index inside the role's 4 waves
     const bool producer = C::WS && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;      // wave-uniform
@@ -596,21 +598,81 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                 int ab = a_base;
                 asm volatile("" : "+v"(ab));                 // no cross-tap CSE of LDS reads (see conv_kernel.h)
                 __builtin_assume((ab & 7) == 0);
+                // operand reads of group gg (same chunk): A fragment of M-tile t, hi plane / lo plane
+                auto rd_a = [&](int gg, int t) __attribute__((always_inline)) {
+                    const int tp = gg >> 1, jj = gg & 1, kyy = tp / C::KS, kxx = tp % C::KS;
+                    a[t] = *reinterpret_cast<const h8*>(&lds[ab + (t * C::RPM * C::STRIDE + kyy) * RSH + kxx * PSH + jj * 16]);
+                };
+                auto rd_al = [&](int gg, int t) __attribute__((always_inline)) {
+                    const int tp = gg >> 1, jj = gg & 1, kyy = tp / C::KS, kxx = tp % C::KS;
+                    al[t] = *reinterpret_cast<const h8*>(&lds[ab + (t * C::RPM * C::STRIDE + kyy) * RSH + kxx * PSH + KC + jj * 16]);
+                };
                 if constexpr (!(C::ABL & 8)) {
+                    if (!kPipe || g == 0) {                  // (kPipe: groups 1.. were read under the previous group's MFMAs)
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) {
-                        a[t] = *reinterpret_cast<const h8*>(&lds[ab + (t * C::RPM * C::STRIDE + ky) * RSH + kx * PSH + j * 16]);
-                        if constexpr (C::SPLIT)
-                            al[t] = *reinterpret_cast<const h8*>(&lds[ab + (t * C::RPM * C::STRIDE + ky) * RSH + kx * PSH + KC + j * 16]);
+                        for (int t = 0; t < MT; ++t) {
+                            rd_a(g, t);
+                            if constexpr (C::SPLIT) rd_al(g, t);
+                        }
                     }
                 }
                 const h8 bq = ring[g % PF][0];
                 h8 bl;
                 if constexpr (C::SPLIT) bl = ring[g % PF][1];
-                if constexpr (!(C::ABL & 4)) {
+                // (kPipe refills each plane of the ring slot right behind the last MFMA that reads it -- below -- so that the old
+                // fragment and its in-flight successor never hold registers at the same time: the pipelined reads need them)
+                if constexpr (!(C::ABL & 4) && !kPipe) {
 #pragma unroll
                     for (int pl_ = 0; pl_ < C::PLANES; ++pl_)      // wraps into the next chunk / tail pad
                         ring[g % PF][pl_] = wload(wc + (unsigned)((g + PF) * GH + pl_ * 512));
+                }
+                if constexpr (kPipe) {
+                    // Software-pipelined operand reads (MFMA waves of the wave-specialised tile): the NEXT group's A fragments are
+                    // read under THIS group's MFMAs, into the registers the group has just finished with -- no extra registers.
+                    // SPLIT order hi*hi, hi*lo, lo*hi: after the 8 MFMAs that use the hi fragments a[0..3] are dead and the next
+                    // group's hi reads fly under the four lo*hi MFMAs (128 matrix-pipe cycles ~ the LDS latency); each lo fragment
+                    // is re-read right behind its own lo*hi MFMA and is not needed for 8 MFMAs.  Without this every group began with
+                    // 8 ds_read_b128 and an lgkmcnt wait in front of its first MFMA, covered only by the SIMD's other MFMA wave
+                    // (tools/ws_stamps.py: a wave keeps the pipe ~58 % busy alone).  sched_barriers pin the order: hipcc sinks the
+                    // reads back in front of their own MFMAs otherwise (round 3's persistent kernel: 0.76 -> 0.70 ms).
+                    const bool nxt_in_chunk = g + 1 < GPC;
+                    if constexpr (C::SPLIT) {
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) acc[t] = mfma_32x32x16(a[t], bq, acc[t]);
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) acc[t] = mfma_32x32x16(a[t], bl, acc[t]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (!(C::ABL & 4)) ring[g % PF][1] = wload(wc + (unsigned)((g + PF) * GH + 512));      // (lo plane: dead now)
+                        if constexpr (!(C::ABL & 8)) {
+                            if (nxt_in_chunk) {
+#pragma unroll
+                                for (int t = 0; t < MT; ++t) rd_a(g + 1, t);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) {
+                            acc[t] = mfma_32x32x16(al[t], bq, acc[t]);
+                            if constexpr (!(C::ABL & 8)) {
+                                if (nxt_in_chunk) rd_al(g + 1, t);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (!(C::ABL & 4)) ring[g % PF][0] = wload(wc + (unsigned)((g + PF) * GH));
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) {
+                            acc[t] = mfma_32x32x16(a[t], bq, acc[t]);
+                            if constexpr (!(C::ABL & 8)) {
+                                if (nxt_in_chunk) rd_a(g + 1, t);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (!(C::ABL & 4)) ring[g % PF][0] = wload(wc + (unsigned)((g + PF) * GH));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    continue;
                 }
                 // MFMA m of the group: term m / MT (hi*hi, lo*hi, hi*lo; lo*lo <= 2^-22 of the product is dropped), tile m % MT
                 auto mfma_at = [&](int m) {

@@ -48,12 +48,12 @@ for _ in range(3):
 ms = e0.elapsed_time(e1)
 T = big.view(torch.int64)[: rows * 16].reshape(rows, 16).cpu().numpy().astype(np.int64)
 M, P = T[: nblocks * 4], T[nblocks * 4:]
-xcc = M[:, 14] & 0xF
-span = max(M[xcc == x][:, 12].max() - M[xcc == x][:, 0].min() for x in np.unique(xcc))
-tick = ms * 1e6 / span
 nch = (c0 + c1 + 31) // 32
 life = M[:, 12] - M[:, 0]
-print(f"tile {a.tile}: launch {ms:.4f} ms, {nblocks} workgroups, {tick:.2f} ns per tick, {nch} chunks")
+# tick length: s_memtime counters of different XCDs / SEs have different bases, so the launch span cannot be read off them; with two
+# workgroups resident on each of the 256 CUs for the whole launch, mean life x workgroups = 512 x launch time
+tick = ms * 1e6 * 512 / (nblocks * life.mean())
+print(f"tile {a.tile}: launch {ms:.4f} ms, {nblocks} workgroups, ~{tick:.3f} ns per tick (= {1 / tick:.2f} GHz counter), {nch} chunks")
 print(f"MFMA waves: life {life.mean() * tick / 1e3:.2f} us; inside the per-chunk barriers {M[:, 15].mean() * tick / 1e3:.2f} us = {M[:, 15].sum() / life.sum():.3f} of their life "
       f"(p10 {np.percentile(M[:, 15] / life, 10):.3f}, p90 {np.percentile(M[:, 15] / life, 90):.3f})")
 seg = {"entry -> first chunk staged (barrier passed)": M[:, 2] - M[:, 0]}
