@@ -201,8 +201,30 @@ __device__ __forceinline__ float silu16_f(float v2, float ksilu) {
 // channels per workgroup); 2 = 2 x 2 (wave = half of the M-tiles x one of TWO N-tiles: 64 channels per workgroup) -- used for
 // the LAST channel block of a layer whose channel count leaves at most 64 channels there (cout = 192: 128 + 64), where the
 // 1 x 4 layout would leave two of the four waves without output channels.
+// XCD-aware workgroup order.  The dispatcher deals consecutive workgroup ids (x fastest, then y) round-robin over the chip's 8 XCDs,
+// each with its own L2: neighbouring spatial tiles -- which share 41 % of an 8 x 16 tile's 10 x 18 halo -- and the channel blocks of one
+// tile -- which read the SAME input -- then sit behind eight different L2s and every one of them fetches the shared bytes from beyond
+// it.  Remapped so that XCD x works through ONE contiguous range of (tile, channel block) pairs, blocks of a tile adjacent, those
+// reads hit its L2 (measured traffic: profiles/r04_*_traffic*.json).  A bijection of [0, gx gy) for any grid size; results do not
+// change (which workgroup computes a tile is not observable).  ABL 8192 (tuning build): the plain order.
+__device__ __forceinline__ int xcd_contiguous(int id, int n) {
+    const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+template <class C>
+__device__ __forceinline__ void conv16_block(int& bx, int& by) {
+    bx = blockIdx.x;
+    by = blockIdx.y;
+    if constexpr (!(C::ABL & 8192)) {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int s = xcd_contiguous(by * gx + bx, gx * gy);
+        if (gy == 1) { bx = s; }
+        else { bx = s / gy; by = s - bx * gy; }
+    }
+}
+
 template <class C, int STG, int WM>
-__device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H* lds_all) {
+__device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H* lds_all, int bx, const int by) {
     constexpr bool kGN = STG == 1 || STG == 2, kSILU = STG == 2 || STG == 3;
     using H = typename C::H;                                       // 16-bit storage / operand type: _Float16 or __bf16
     using h8 = __attribute__((ext_vector_type(8))) H;
@@ -221,7 +243,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wv % WN, wm = wv / WN;
 
-    int bx = blockIdx.x;
+    const int bx0 = bx;
     const int tx = bx % p.tiles_x;
     bx /= p.tiles_x;
     const int ty = bx % p.tiles_y;
@@ -453,7 +475,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     // ---- MFMA operand addressing ----
     const int li = lane & 31, lh = lane >> 5;
     const int a_base = ((li >> C::LOGTW) * C::STRIDE + wm * MT * C::RPM * C::STRIDE) * RSH + ((li & (C::TW - 1)) * C::STRIDE) * PSH + lh * 8;
-    const int ntile = blockIdx.y * 4 + wn;
+    const int ntile = by * 4 + wn;
     const bool nvalid = ntile * 32 < p.Cout;
     // packed weights: [ntile][chunk][tap][j = 0..1][plane][lane][8 halves] -> one group = GH halves (1 KiB per plane)
     constexpr int GH = 512 * C::PLANES;
@@ -797,7 +819,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             if (!nok) am = 0.f;
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) am = fmaxf(am, __shfl_xor(am, off));
-            if (lane == 0) amax_publish(p.amax_out, b, (blockIdx.x * 4 + wv) * 5 + blockIdx.y, am);
+            if (lane == 0) amax_publish(p.amax_out, b, (bx0 * 4 + wv) * 5 + by, am);
         }
         return;
     }
@@ -977,14 +999,16 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params p) {
     // two halo images: chunk c+1 is staged into the other one WHILE chunk c's MFMAs run (one unit per MFMA group), one
     // barrier per chunk (DB = 0: one image, two barriers)
     __shared__ __attribute__((aligned(16))) typename C::H lds_all[(C::DB ? 2 : 1) * C::LDS_HALVES];
+    int bx, by;
+    conv16_block<C>(bx, by);
     if constexpr (C::MT == 4) {
         // block-uniform: the last channel block of a layer with <= 64 channels left runs the 2 x 2 wave layout
-        if (blockIdx.y == gridDim.y - 1 && conv16_tail_2x2(p.Cout, C::MT)) {
-            conv16_body<C, STG, 2>(p, lds_all);
+        if (by == (int)gridDim.y - 1 && conv16_tail_2x2(p.Cout, C::MT)) {
+            conv16_body<C, STG, 2>(p, lds_all, bx, by);
             return;
         }
     }
-    conv16_body<C, STG, 1>(p, lds_all);
+    conv16_body<C, STG, 1>(p, lds_all, bx, by);
 }
 
 // wave-specialised form: 8 waves, two workgroups per CU = 4 waves per SIMD (<= 128 VGPRs)
@@ -992,13 +1016,15 @@ template <class C, int STG>
 __global__ __launch_bounds__(512, 4) void conv16_ws_kernel(const Conv16Params p) {
     static_assert(C::WS && C::DB, "conv16_ws_kernel runs the WS configurations");
     __shared__ __attribute__((aligned(16))) typename C::H lds_all[2 * C::LDS_HALVES];
+    int bx, by;
+    conv16_block<C>(bx, by);
     if constexpr (C::MT == 4) {
-        if (blockIdx.y == gridDim.y - 1 && conv16_tail_2x2(p.Cout, C::MT)) {
-            conv16_body<C, STG, 2>(p, lds_all);
+        if (by == (int)gridDim.y - 1 && conv16_tail_2x2(p.Cout, C::MT)) {
+            conv16_body<C, STG, 2>(p, lds_all, bx, by);
             return;
         }
     }
-    conv16_body<C, STG, 1>(p, lds_all);
+    conv16_body<C, STG, 1>(p, lds_all, bx, by);
 }
 
 #ifdef CDX_TUNING
