@@ -83,7 +83,7 @@ int conv16_dispatch(int ks, int stride, int logtw, int mt, bool bf, const Conv16
             case 6: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 2, 0, 1, 0, 1>>(p, stream);      // ... producers stage only the first chunk (the MFMA waves' bound)
             case 3: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 1, 0, 1, 0, 1>>(p, stream);      // ... no epilogue
             case 2: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 3, 0, 1, 0, 1>>(p, stream);      // ... neither
-            case 9: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 8192, 0, 1, 0, 1>>(p, stream);   // ... plain workgroup order (no XCD-contiguous remap)
+            case 9: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 8192, 0, 1, 0, 1>>(p, stream);   // ... XCD-contiguous workgroup order (measured, not shipped)
             case 8: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 4096, 0, 1, 0, 1>>(p, stream);   // ... operand reads NOT software-pipelined (round 3's MFMA waves)
             default: return CDX_ENOTSUP;
         }

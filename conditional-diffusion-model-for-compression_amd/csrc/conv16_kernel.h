@@ -201,12 +201,13 @@ __device__ __forceinline__ float silu16_f(float v2, float ksilu) {
 // channels per workgroup); 2 = 2 x 2 (wave = half of the M-tiles x one of TWO N-tiles: 64 channels per workgroup) -- used for
 // the LAST channel block of a layer whose channel count leaves at most 64 channels there (cout = 192: 128 + 64), where the
 // 1 x 4 layout would leave two of the four waves without output channels.
-// XCD-aware workgroup order.  The dispatcher deals consecutive workgroup ids (x fastest, then y) round-robin over the chip's 8 XCDs,
-// each with its own L2: neighbouring spatial tiles -- which share 41 % of an 8 x 16 tile's 10 x 18 halo -- and the channel blocks of one
-// tile -- which read the SAME input -- then sit behind eight different L2s and every one of them fetches the shared bytes from beyond
-// it.  Remapped so that XCD x works through ONE contiguous range of (tile, channel block) pairs, blocks of a tile adjacent, those
-// reads hit its L2 (measured traffic: profiles/r04_*_traffic*.json).  A bijection of [0, gx gy) for any grid size; results do not
-// change (which workgroup computes a tile is not observable).  ABL 8192 (tuning build): the plain order.
+// XCD-contiguous workgroup order -- an EXPERIMENT (ABL 8192, tuning build only), measured and not shipped.  The dispatcher deals
+// consecutive workgroup ids (x fastest, then y) round-robin over the chip's 8 XCDs, each with its own L2; remapped, XCD x works
+// through ONE contiguous range of (tile, channel block) pairs, so that neighbouring tiles (41 % of an 8 x 16 tile's halo is shared)
+// and the channel blocks of a tile (the same input) sit behind one L2.  Round 4, in-process A/B (tools/session/gpu_r4c.sh):
+// 256^2 128->128 +0.6 %, 256->128 0, 128^2 256->256 +0.6 %, 256^2 384->384 (3 blocks) +2.3 %, 512^2 192->192 (128 + 64-channel tail
+// block) -5.5 %; FETCH_SIZE per launch 631 vs 622 MiB, 2.81 vs 2.82 GiB, 1.93 vs 2.07 GiB -- the L2s do not turn the shared bytes into
+// hits in either order (the extra fetch equals the whole halo overlap: 64 resident workgroups stream 14 MB through a 4 MB L2).
 __device__ __forceinline__ int xcd_contiguous(int id, int n) {
     const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
@@ -215,7 +216,7 @@ template <class C>
 __device__ __forceinline__ void conv16_block(int& bx, int& by) {
     bx = blockIdx.x;
     by = blockIdx.y;
-    if constexpr (!(C::ABL & 8192)) {
+    if constexpr ((C::ABL & 8192) != 0) {
         const int gx = gridDim.x, gy = gridDim.y;
         const int s = xcd_contiguous(by * gx + bx, gx * gy);
         if (gy == 1) { bx = s; }
@@ -262,6 +263,14 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             __builtin_amdgcn_sched_barrier(0);
             if (lane == 0)
                 reinterpret_cast<unsigned long long*>(p.stats)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 16 + k] = t;
+            // the constant 100 MHz counter beside the shader-clock one, at entry (slot 11) and at the last stamp (slot 10): the clock
+            // the chip held over this wave's life = delta s_memtime / delta s_memrealtime x 100 MHz (MI355X_MICROARCH.md, DVFS give-back 6)
+            if (k == 0 || k == 12) {
+                unsigned long long rt;
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt) : : "memory");
+                if (lane == 0)
+                    reinterpret_cast<unsigned long long*>(p.stats)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 16 + (k == 0 ? 11 : 10)] = rt;
+            }
         }
     };
     // (WS, ABL & 512) barrier accounting: ticks a wave spends inside the per-chunk __syncthreads (slot 15 of an MFMA wave; the

@@ -53,7 +53,13 @@ life = M[:, 12] - M[:, 0]
 # tick length: s_memtime counters of different XCDs / SEs have different bases, so the launch span cannot be read off them; with two
 # workgroups resident on each of the 256 CUs for the whole launch, mean life x workgroups = 512 x launch time
 tick = ms * 1e6 * 512 / (nblocks * life.mean())
-print(f"tile {a.tile}: launch {ms:.4f} ms, {nblocks} workgroups, ~{tick:.3f} ns per tick (= {1 / tick:.2f} GHz counter), {nch} chunks")
+rt = (M[:, 10] - M[:, 11]).astype(np.float64)          # 100 MHz ticks over the same span
+okc = rt > 0
+clk = np.median(life[okc] / rt[okc]) * 0.1            # GHz
+tick = 1.0 / clk
+print(f"tile {a.tile}: launch {ms:.4f} ms, {nblocks} workgroups, {nch} chunks; in-kernel clock (s_memtime / s_memrealtime, median over waves) {clk:.3f} GHz "
+      f"(p10 {np.percentile(life[okc] / rt[okc], 10) * 0.1:.3f}, p90 {np.percentile(life[okc] / rt[okc], 90) * 0.1:.3f}); "
+      f"mean residency implied by 2 workgroups per CU: {ms * 1e3 * 512 / nblocks:.1f} us per workgroup")
 print(f"MFMA waves: life {life.mean() * tick / 1e3:.2f} us; inside the per-chunk barriers {M[:, 15].mean() * tick / 1e3:.2f} us = {M[:, 15].sum() / life.sum():.3f} of their life "
       f"(p10 {np.percentile(M[:, 15] / life, 10):.3f}, p90 {np.percentile(M[:, 15] / life, 90):.3f})")
 seg = {"entry -> first chunk staged (barrier passed)": M[:, 2] - M[:, 0]}
