@@ -89,6 +89,11 @@ struct Conv16Params {
     // launch is stored at (ostep y + ody, ostep x + odx) of the full-resolution tensor, the halo starts pady / padx pixels up / left
     // of the tile, and the launch's GroupNorm-sum slots start at slot_base of nslots_total.  Plain launches: 1, 0, 0, PAD, PAD, 0, 0.
     int ostep, ody, odx, pady, padx, slot_base, nslots_total;
+    // Wave-specialised kernels: a workgroup walks a SEQUENCE of `seq` consecutive spatial tiles (grid.x = ceil(tiles / seq)): the
+    // producer waves load and stage the next tile's first chunks under the current tile's last MFMAs, so only the first tile of a
+    // sequence waits for its halo (tools/ws_stamps.py: that wait was 18 % of an MFMA wave's life in the float32 tile, 30 % in the
+    // 16-bit tile).  0 = let the launcher choose; the 4-wave kernels ignore it (one tile per workgroup).
+    int seq;
     int act_exp;
     const unsigned* amax[2]; // [B][CDX_AMAX_WORDS] float32 bit patterns (max over the words = max |x| of the image) per source, or null
     unsigned* amax_out;      // [B][CDX_AMAX_WORDS] or null: atomic max of one word with the bit pattern of the wave's max |out|
@@ -244,14 +249,13 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wv % WN, wm = wv / WN;
 
-    const int bx0 = bx;
-    const int tx = bx % p.tiles_x;
-    bx /= p.tiles_x;
-    const int ty = bx % p.tiles_y;
-    const int b = bx / p.tiles_y;
-    const int oy0 = ty * C::TH, ox0 = tx * C::TW;
-    const int oy0w = oy0 + ((wm * MT * 32) >> C::LOGTW);           // first output row of THIS wave's M-tiles
-    const int iy0 = oy0 * C::STRIDE - (C::KS == 2 ? p.pady : C::PAD), ix0 = ox0 * C::STRIDE - (C::KS == 2 ? p.padx : C::PAD);
+    // The workgroup's tile sequence: tiles T0 .. T0 + nseq - 1 of the launch's tiles_x * tiles_y * B spatial tiles (4-wave kernels:
+    // one tile).  Everything below that depends on the tile is (re)computed by set_tile().
+    const int ntiles_all = p.tiles_x * p.tiles_y * p.B;
+    const int seq = C::WS ? (p.seq > 0 ? p.seq : 1) : 1;
+    const int T0 = bx * seq;
+    const int nseq = C::WS ? (ntiles_all - T0 < seq ? ntiles_all - T0 : seq) : 1;
+    int tile_id, tx, ty, b, oy0, ox0, oy0w, iy0, ix0;
     // ABL & 512 (diagnostic build): s_memtime stamps per wave at the phase boundaries, 16 per wave, into the buffer behind
     // p.stats (which then holds no sums): 0 entry, 1 first loads issued, 2 first chunk staged (barrier passed), 3 + c chunk c
     // done (c < 8), 12 stores issued, 13 HW_ID, 14 XCC_ID  (digest: tools/conv_bench.py --stamps)
@@ -310,21 +314,38 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         }
     }
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
-    const ActScale asc = act_scale_of<C::SPLIT != 0, kGN>(p, b);
+    ActScale asc;
 
     // ---- loader: thread -> (pixel slot pl of 64, channel octet q of 4) ----
     const int q = tid & 3, pl = tid >> 2;
     int soff[NPASS];                                  // pixel index inside image b
     unsigned vmask = 0;
+    int cur_src = -1;                                 // source the halo loads are bound to (-1: rebind at the next issue_loads)
+    auto set_tile = [&](int T) __attribute__((always_inline)) {
+        tile_id = T;
+        tx = T % p.tiles_x;
+        const int r = T / p.tiles_x;
+        ty = r % p.tiles_y;
+        b = r / p.tiles_y;
+        oy0 = ty * C::TH;
+        ox0 = tx * C::TW;
+        oy0w = oy0 + ((wm * MT * 32) >> C::LOGTW);           // first output row of THIS wave's M-tiles
+        iy0 = oy0 * C::STRIDE - (C::KS == 2 ? p.pady : C::PAD);
+        ix0 = ox0 * C::STRIDE - (C::KS == 2 ? p.padx : C::PAD);
+        asc = act_scale_of<C::SPLIT != 0, kGN>(p, b);
+        vmask = 0;
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-        const int hp = i * 64 + pl;
-        const int hy = hp / C::HW, hx = hp - hy * C::HW;
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        const bool ok = hp < C::NPIX && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-        soff[i] = ok ? (iy >> p.ups) * p.Win + (ix >> p.ups) : 0;
-        vmask |= ok ? (1u << i) : 0u;
-    }
+        for (int i = 0; i < NPASS; ++i) {
+            const int hp = i * 64 + pl;
+            const int hy = hp / C::HW, hx = hp - hy * C::HW;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = hp < C::NPIX && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+            soff[i] = ok ? (iy >> p.ups) * p.Win + (ix >> p.ups) : 0;
+            vmask |= ok ? (1u << i) : 0u;
+        }
+        cur_src = -1;                                 // (the buffer resource covers image b of the source)
+    };
+    set_tile(T0);
     float pre[NPASS][8];
     f32x4 gsc[2], gsh[2];
     bool cvalid;
@@ -339,7 +360,6 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     // after the activation, so neither GroupNorm's shift nor NaN / Inf in the dummy can leak into the padding.
     unsigned voff[NPASS];
     __amdgpu_buffer_rsrc_t srs;
-    int cur_src = -1;
     const unsigned esz = (C::SPLIT || p.src_f32) ? 4u : 2u;
     auto bind_source = [&](int sidx) {
         const unsigned cs = (unsigned)p.csrc[sidx];
@@ -456,18 +476,29 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
 
     if constexpr (C::WS) {
         if (producer) {      // ---- producer waves: stage every chunk, one barrier per chunk in step with the MFMA waves ----
-            issue_loads(0);
+            // The chunks of the workgroup's tile sequence form ONE flat sequence k = tile * nchunks + chunk, staged into image k & 1:
+            // while the MFMA waves work on k, chunk k + 1 is staged and the halo loads of k + 2 are issued -- across tile boundaries
+            // too, so the next tile's first chunk is in LDS when the MFMA waves leave the current tile's epilogue.  (Staging chunk k
+            // reads the tile state -- padding mask, activation scale -- that issue(k) set: program order is stage(k + 1), issue(k + 2).)
+            const int K = nseq * p.nchunks;
+            int kt = 0, kc = 0;                       // (tile in the sequence, chunk) of the NEXT issue
+            auto issue_next = [&]() __attribute__((always_inline)) {
+                if (kc == 0 && kt > 0) set_tile(T0 + kt);
+                issue_loads(kc);
+                if (++kc == p.nchunks) { kc = 0; ++kt; }
+            };
+            issue_next();
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
-            if (p.nchunks > 1 && !(C::ABL & 2)) issue_loads(1);
+            if (K > 1 && !(C::ABL & 2)) issue_next();
             __syncthreads();
-            for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-                H* nxt = lds_all + ((chunk + 1) & 1) * C::LDS_HALVES;
-                if (chunk + 1 < p.nchunks && !(C::ABL & 2)) {
+            for (int k = 0; k < K; ++k) {
+                H* nxt = lds_all + ((k + 1) & 1) * C::LDS_HALVES;
+                if (k + 1 < K && !(C::ABL & 2)) {
                     const unsigned long long t0 = memtime();
 #pragma unroll
                     for (int i = 0; i < NPASS; ++i) write_pass(nxt, i);
-                    if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
+                    if (k + 2 < K) issue_next();
                     stage_ticks += memtime() - t0;
                 }
                 timed_barrier();
@@ -495,10 +526,6 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     auto wload = [&](unsigned half_off) { return __builtin_bit_cast(h8, buf_load4(wrs, wlane, half_off * 2u)); };
 
     f32x16 acc[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     // bias + temb + residual enter through the accumulator init (SPLIT: scaled by 1/unscale, a power of two: exact), so the
     // residual tile is fetched under the first chunk's staging instead of standing between the last MFMA and the stores
     // (measured: the epilogue's residual loads were 6 % of the SPLIT kernel).  Accumulator layout of the 32x32 MFMA: lane =
@@ -521,6 +548,9 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
 #endif
     auto add_terms = [&](auto first_, float macc, float inv) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_)::value;
+        int lane_i = (int)(wlane >> 4);                       // (opaque, as in the epilogue: nothing of the NEXT tile's init may be
+        asm volatile("" : "+v"(lane_i));                      //  precomputed and carried through the current tile's MFMA loop)
+        const int li = lane_i & 31, lh = lane_i >> 5;
         const int n = ntile * 32 + li;
         if (!(nvalid && n < p.Cout)) return;
         float add = 0.f;
@@ -563,44 +593,330 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                 for (int r = 0; r < 16; ++r) acc[t][r] = FIRST ? add : fmaf(acc[t][r], macc, add);
         }
     };
-    if constexpr (kAccInit) {
-        if (!asc.late) add_terms(std::true_type{}, 1.f, asc.inv);
-    }
-
     h8 ring[PF][C::PLANES];
-#pragma unroll
-    for (int j = 0; j < PF; ++j)
-#pragma unroll
-        for (int pl_ = 0; pl_ < C::PLANES; ++pl_) ring[j][pl_] = wload(j * GH + pl_ * 512);
 
-    // packed-epilogue layout (see below)
-    const int q4 = li & 3;
-    const int cq = ntile * 32 + (li & ~3);                    // first of this quad's 4 channels
-    const bool quad_ok = nvalid && cq < p.Cout;               // (cout is a multiple of 4 or the tail is zero-weighted)
     // staging schedule inside a chunk: passes at groups G0 .. G0+NPASS-1, the loads of the chunk after next right behind
     constexpr int NU = UPP * NPASS;
     constexpr int G0 = GPC > NU + 1 ? GPC - NU - 1 : 0;
     static_assert(NU + 1 <= GPC || GPC <= 2 || !C::DB, "staging units must fit in the chunk's groups (1x1: done after the groups)");
-    if constexpr (!C::WS) {
-        issue_loads(0);
-        stamp(1);
+    // ---- epilogue of ONE tile (a lambda: the tile loop below runs it once per tile of the workgroup's sequence) ----
+    auto run_epilogue = [&]() __attribute__((always_inline)) {
+    // ---- epilogue ----
+    if (!nvalid) return;
+    // The lane's coordinates are re-derived from an OPAQUE copy of the lane id: the epilogue now sits inside the tile loop, and
+    // everything in it that does not depend on the tile (store offsets, channel indices, masks) would otherwise be hoisted in
+    // front of that loop and held in registers across the MFMA loop -- which has none to spare (measured: 80 - 1000 spilled
+    // dwords, some inside the chunk loop).  A handful of integer instructions per tile instead.
+    int lane_e = (int)(wlane >> 4);                           // (wlane = 16 lane is live across the loop anyway)
+    asm volatile("" : "+v"(lane_e));
+    const int li = lane_e & 31, lh = lane_e >> 5;
+    // packed-epilogue layout (see below)
+    const int q4 = li & 3;
+    const int cq = ntile * 32 + (li & ~3);                    // first of this quad's 4 channels
+    const bool quad_ok = nvalid && cq < p.Cout;               // (cout is a multiple of 4 or the tail is zero-weighted)
+    if constexpr (C::ABL & 1) {
+        float keep = 0.f;
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
-        if (p.nchunks > 1 && !(C::ABL & 2)) issue_loads(1);
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) keep += acc[t][r];
+        if (keep == 123.456f) static_cast<float*>(p.out)[0] = keep;
+        return;
     }
-    __syncthreads();
-    stamp(2);
-    h8 a[MT], al[MT];
-    if constexpr (C::ABL & 8) {                 // ablation: operands read once
+    const int n = ntile * 32 + li;
+    const bool nok = n < p.Cout;
+    if constexpr (C::SPLIT) {
+        // float32 out, straight from the accumulator layout (lane = channel): one dword per lane and register, 128 B per half
+        // wave and pixel -- full cache lines, no cross-lane transposes, no per-store address arithmetic (scalar offset per
+        // register, lane offset fixed), GroupNorm sums per lane = per channel.  (The 4 x 4 quad-transposed form below cost
+        // ~43 vector instructions per 16-byte store, 8 of them quarter-rate integer multiplies for the flat address.)
+        constexpr int ROWS = (MT * 32) >> C::LOGTW;
+        const bool full = oy0w + ROWS <= p.Hout && ox0 + C::TW <= p.Wout;          // wave-uniform
+        // (phase launches: output pixel (y, x) lands at (os y + ody, os x + odx) of the os-times larger tensor; os = 1 otherwise)
+        const unsigned os = (unsigned)p.ostep, WoutF = (unsigned)p.Wout * os;
+        const size_t first = (((size_t)b * p.Hout * os + (size_t)oy0w * os + p.ody) * WoutF + (size_t)ox0 * os + p.odx) * p.out_ld;
+        const size_t total = (size_t)p.B * p.Hout * os * WoutF * p.out_ld;
+        const size_t left = first < total ? (total - first) * 4 : 1;              // (tile rows wholly past the image: a resource no dword fits into)
+        constexpr unsigned kDrop = 0x80000000u;                                    // beyond any resource: the store is dropped
+        const __amdgpu_buffer_rsrc_t ors = buf_rsrc(static_cast<float*>(p.out) + (first < total ? first : 0), left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)left);
+        const unsigned vbase = nok ? ((unsigned)(4 * lh) * os * (unsigned)p.out_ld + (unsigned)n) * 4u : kDrop;
+        float un = asc.un;
+        if (asc.late && (p.residual || !bias_late)) {   // (rare: see ActScale) outputs first, then the additive terms at their own scale
+            add_terms(std::false_type{}, un, 1.f);   // (lanes without an output channel keep raw accumulators: never stored)
+            un = 1.f;
+        }
+        float addv = 0.f;                            // bias + temb of this lane's channel, added by the store loop's FMA
+        if (bias_late && nok) {
+            addv = p.bias ? p.bias[n] : 0.f;
+            if (p.temb) addv += p.temb[(size_t)b * p.temb_ld + n];
+        }
+        // (the sums variant also serves amax_out: a caller that wants only one of them pays for both)
+        const bool want_stats = (p.stats || p.amax_out) && !(C::ABL & 32);
+        double s1 = 0, s2 = 0;
+        float am = 0.f;
+        auto direct = [&](auto full_, auto has_stats) __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            a[t] = *reinterpret_cast<const h8*>(&lds_all[a_base + t * C::RPM * C::STRIDE * RSH]);
-            al[t] = *reinterpret_cast<const h8*>(&lds_all[a_base + t * C::RPM * C::STRIDE * RSH + 16]);
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mb = t * 32 + 8 * (r >> 2) + (r & 3);
+                    const int row = mb >> C::LOGTW, col = mb & (C::TW - 1);
+                    const unsigned soff = ((unsigned)row * os * WoutF + (unsigned)col * os) * (unsigned)p.out_ld * 4u;
+                    const float x = fmaf(acc[t][r], un, addv);
+                    bool ok = true;
+                    if constexpr (!decltype(full_)::value) ok = oy0w + row < p.Hout && ox0 + col + 4 * lh < p.Wout;
+                    if constexpr (decltype(has_stats)::value) {
+                        const float xs = ok ? x : 0.f;
+                        const double d = (double)xs;
+                        s1 += d;
+                        s2 = fma(d, d, s2);
+                        am = fmaxf(am, fabsf(xs));                      // (NaN skipped, Inf kept)
+                    }
+                    buf_store1(ors, ok ? vbase : kDrop, soff, x);       // (last use of x: the tie in buf_store1 then costs no copy)
+                }
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        if (full) { if (want_stats) direct(T_{}, T_{}); else direct(T_{}, F_{}); }
+        else      { if (want_stats) direct(F_{}, T_{}); else direct(F_{}, F_{}); }
+        stamp(12);
+        if constexpr (C::WS && (C::ABL & 512) != 0) {
+            if (lane == 0) reinterpret_cast<unsigned long long*>(p.stats)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 16 + 15] = bar_ticks;
+        }
+        if (p.stats && !(C::ABL & 32)) {
+            s1 += __shfl_xor(s1, 32);                  // the two lane halves hold different pixels of the same channel
+            s2 += __shfl_xor(s2, 32);
+            if (lh == 0 && nok) {
+                const int slot = p.slot_base + (ty * p.tiles_x + tx) * p.stats_wm + (WM == 2 ? wm : 0);
+                const int nslots = p.nslots_total ? p.nslots_total : p.tiles_y * p.tiles_x * p.stats_wm;
+                double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + n) * 2;
+                o[0] = s1;
+                o[1] = s2;
+                if (WM == 1 && p.stats_wm == 2) {      // a 1 x 4 block of a layer whose LAST block runs 2 x 2: second slot = 0
+                    o[(size_t)p.Cout * 2] = 0.0;
+                    o[(size_t)p.Cout * 2 + 1] = 0.0;
+                }
+            }
+        }
+        if (p.amax_out && !(C::ABL & 32)) {
+            if (!nok) am = 0.f;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) am = fmaxf(am, __shfl_xor(am, off));
+            if (lane == 0) amax_publish(p.amax_out, b, (tile_id * 4 + wv) * 5 + by, am);
+        }
+        return;
+    }
+    if constexpr (kAccInit) {
+        // 16-bit out from the accumulator layout: lanes (2c, 2c+1) exchange one value per register pair (r, r+1 = the next
+        // pixel of the row), so the even lane stores channels (2c, 2c+1) of pixel r and the odd lane those of pixel r+1 --
+        // one packed dword per lane, 64 B per pixel and half wave, scalar offset per pair, GroupNorm sums per lane = channel
+        // (from the float32 accumulators, before rounding).  5 vector instructions per pair + the sums, where the
+        // quad-transposed form below cost ~30 per 8-byte store.
+        if (!p.out_f32 && !(p.Cout & 1)) {
+            constexpr int ROWS = (MT * 32) >> C::LOGTW;
+            const bool full = oy0w + ROWS <= p.Hout && ox0 + C::TW <= p.Wout;      // wave-uniform
+            const size_t first = (((size_t)b * p.Hout + oy0w) * p.Wout + ox0) * p.out_ld;
+            const size_t total = (size_t)p.B * p.Hout * p.Wout * p.out_ld;
+            const size_t left = first < total ? (total - first) * 2 : 1;          // (tile rows wholly past the image: a resource no dword fits into)
+            constexpr unsigned kDrop = 0x80000000u;
+            const __amdgpu_buffer_rsrc_t ors = buf_rsrc(static_cast<H*>(p.out) + (first < total ? first : 0), left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)left);
+            const int odd = li & 1;
+            const unsigned vbase = nok ? ((unsigned)(4 * lh + odd) * (unsigned)p.out_ld + (unsigned)(n - odd)) * 2u : kDrop;
+            const unsigned rot = odd ? 16u : 0u;
+            const bool want_stats = p.stats && !(C::ABL & 32);
+            double s1 = 0, s2 = 0;
+            auto direct = [&](auto full_, auto has_stats) __attribute__((always_inline)) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int mb = t * 32 + 8 * (r >> 2) + (r & 3);
+                        const int row = mb >> C::LOGTW, col = mb & (C::TW - 1);
+                        const unsigned soff = ((unsigned)row * (unsigned)p.Wout + (unsigned)col) * (unsigned)p.out_ld * 2u;
+                        const float x0 = acc[t][r], x1 = acc[t][r + 1];
+                        bool ok0 = true, ok1 = true;
+                        if constexpr (!decltype(full_)::value) {
+                            const bool rok = oy0w + row < p.Hout;
+                            ok0 = rok && ox0 + col + 4 * lh < p.Wout;
+                            ok1 = rok && ox0 + col + 4 * lh + 1 < p.Wout;
+                        }
+                        if constexpr (decltype(has_stats)::value) {
+                            const double d0 = ok0 ? (double)x0 : 0.0, d1 = ok1 ? (double)x1 : 0.0;
+                            s1 += d0;
+                            s2 = fma(d0, d0, s2);
+                            s1 += d1;
+                            s2 = fma(d1, d1, s2);
+                        }
+                        const float got = quad_xor1(odd ? x0 : x1);          // the neighbour lane's value for MY pixel
+                        const float keep = odd ? x1 : x0;
+                        using h2 = __attribute__((ext_vector_type(2))) H;
+                        const unsigned pk = __builtin_bit_cast(unsigned, h2{(H)keep, (H)got});      // even lane: (n, n+1)
+                        buf_store1(ors, (odd ? ok1 : ok0) ? vbase : kDrop, soff, __builtin_amdgcn_alignbit(pk, pk, rot));   // odd: (n-1, n)
+                    }
+            };
+            using T_ = std::true_type;
+            using F_ = std::false_type;
+            if (full) { if (want_stats) direct(T_{}, T_{}); else direct(T_{}, F_{}); }
+            else      { if (want_stats) direct(F_{}, T_{}); else direct(F_{}, F_{}); }
+            stamp(12);
+            if constexpr (C::WS && (C::ABL & 512) != 0) {
+                if (lane == 0) reinterpret_cast<unsigned long long*>(p.stats)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 16 + 15] = bar_ticks;
+            }
+            if (want_stats) {
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (lh == 0 && nok) {
+                    const int slot = (ty * p.tiles_x + tx) * p.stats_wm + (WM == 2 ? wm : 0);
+                    const int nslots = p.tiles_y * p.tiles_x * p.stats_wm;
+                    double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + n) * 2;
+                    o[0] = s1;
+                    o[1] = s2;
+                    if (WM == 1 && p.stats_wm == 2) {
+                        o[(size_t)p.Cout * 2] = 0.0;
+                        o[(size_t)p.Cout * 2 + 1] = 0.0;
+                    }
+                }
+            }
+            return;
         }
     }
+    float add = 0.f;
+    if (nok) {
+        add = p.bias ? p.bias[n] : 0.f;
+        if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
+    }
+    // 16-bit storage -- packed epilogue: 4x4 blocks (4 consecutive pixels x the quad's 4 channels) are transposed across lane quads in
+    // registers, so every lane stores / loads 4 consecutive channels of ONE pixel (8 B fp16, 16 B fp32) -- 4x fewer,
+    // 4x wider memory instructions than the accumulator layout allows.  GroupNorm sums are reduced in that layout.
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    auto epilogue = [&](auto has_res, auto has_stats, auto out32) __attribute__((always_inline)) {
+        using res_t = h4;
+        using rel_t = H;
+        res_t rv[MT][4];
+        if constexpr (decltype(has_res)::value) {      // one batch of 8/16-byte loads (a load in the last chunk instead
+#pragma unroll                                          // would queue the weight ring behind HBM misses: vmcnt is in-order)
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int m = t * 32 + 8 * k + q4 + 4 * lh;
+                    const int oy = min(oy0w + (m >> C::LOGTW), p.Hout - 1), ox = min(ox0 + (m & (C::TW - 1)), p.Wout - 1);
+                    rv[t][k] = *reinterpret_cast<const res_t*>(static_cast<const rel_t*>(p.residual) +
+                                                               (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + (quad_ok ? cq : 0));
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float x[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[c] = kAccInit ? acc[t][4 * k + c] : acc[t][4 * k + c] + add;
+                quad_transpose(x, q4);                        // now: pixel 8k + q4 (+4 lh) of tile t, channels cq..cq+3
+                const int m = t * 32 + 8 * k + q4 + 4 * lh;
+                const int oy = oy0w + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
+                if (quad_ok && oy < p.Hout && ox < p.Wout) {
+                    const size_t pix = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+                    if constexpr (decltype(has_res)::value) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) x[c] += (float)rv[t][k][c];
+                    }
+                    if constexpr (decltype(out32)::value) {
+                        *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + pix * p.out_ld + cq) = f32x4{x[0], x[1], x[2], x[3]};
+                    } else {
+                        *reinterpret_cast<h4*>(static_cast<H*>(p.out) + pix * p.out_ld + cq) =
+                            h4{(H)x[0], (H)x[1], (H)x[2], (H)x[3]};
+                    }
+                    if constexpr (decltype(has_stats)::value) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const double d = (double)x[c];
+                            s1[c] += d;
+                            s2[c] = fma(d, d, s2[c]);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if constexpr (kAccInit) {   // 16-bit storage, bias / temb / residual already in the accumulators
+        if (p.out_f32) epilogue(F_{}, F_{}, T_{});
+        else if (p.stats) epilogue(F_{}, T_{}, F_{});
+        else epilogue(F_{}, F_{}, F_{});
+    } else if (p.out_f32) {
+        if (p.residual) epilogue(T_{}, F_{}, T_{}); else epilogue(F_{}, F_{}, T_{});
+    } else if (p.residual) {
+        if (p.stats) epilogue(T_{}, T_{}, F_{}); else epilogue(T_{}, F_{}, F_{});
+    } else {
+        if (p.stats) epilogue(F_{}, T_{}, F_{}); else epilogue(F_{}, F_{}, F_{});
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {      // the quad's 4 lanes and the two lane halves hold different pixels
+            s1[c] += __shfl_xor(s1[c], 1);
+            s2[c] += __shfl_xor(s2[c], 1);
+            s1[c] += __shfl_xor(s1[c], 2);
+            s2[c] += __shfl_xor(s2[c], 2);
+            s1[c] += __shfl_xor(s1[c], 32);
+            s2[c] += __shfl_xor(s2[c], 32);
+        }
+        if (lh == 0 && q4 == 0 && quad_ok) {
+            // p.stats_wm slots per tile: a layer with a 2 x 2 last block has two (its 1 x 4 blocks fill the first and zero the second)
+            const int slot = (ty * p.tiles_x + tx) * p.stats_wm + (WM == 2 ? wm : 0);
+            const int nslots = p.tiles_y * p.tiles_x * p.stats_wm;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (cq + c < p.Cout) {
+                    double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + cq + c) * 2;
+                    o[0] = s1[c];
+                    o[1] = s2[c];
+                    if (WM == 1 && p.stats_wm == 2) {
+                        o[(size_t)p.Cout * 2] = 0.0;
+                        o[(size_t)p.Cout * 2 + 1] = 0.0;
+                    }
+                }
+            }
+        }
+    }
+    };
+    h8 a[MT], al[MT];
+    // ---- the workgroup's tiles, one after the other (4-wave kernels: one) ----
+    for (int qi = 0; qi < nseq; ++qi) {
+    if (qi > 0) set_tile(T0 + qi);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    if constexpr (kAccInit) {
+        if (!asc.late) add_terms(std::true_type{}, 1.f, asc.inv);
+    }
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+#pragma unroll
+        for (int pl_ = 0; pl_ < C::PLANES; ++pl_) ring[j][pl_] = wload(j * GH + pl_ * 512);
+    if (qi == 0) {
+        if constexpr (!C::WS) {
+            issue_loads(0);
+            stamp(1);
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
+            if (p.nchunks > 1 && !(C::ABL & 2)) issue_loads(1);
+        }
+        __syncthreads();
+        stamp(2);
+        if constexpr (C::ABL & 8) {                 // ablation: operands read once
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                a[t] = *reinterpret_cast<const h8*>(&lds_all[a_base + t * C::RPM * C::STRIDE * RSH]);
+                al[t] = *reinterpret_cast<const h8*>(&lds_all[a_base + t * C::RPM * C::STRIDE * RSH + 16]);
+            }
+        }
+    }
+    const int kbase = qi * p.nchunks;              // image parity runs over the workgroup's flat chunk sequence (producer loop)
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        const H* lds = lds_all + (C::DB ? (chunk & 1) * C::LDS_HALVES : 0);
-        H* nxt = lds_all + (C::DB ? ((chunk + 1) & 1) * C::LDS_HALVES : 0);
+        const H* lds = lds_all + (C::DB ? ((kbase + chunk) & 1) * C::LDS_HALVES : 0);
+        H* nxt = lds_all + (C::DB ? ((kbase + chunk + 1) & 1) * C::LDS_HALVES : 0);
         const bool more = chunk + 1 < p.nchunks && !(C::ABL & 2);
         if (!C::WS && C::DB && (!nvalid || GPC <= 2)) {
             // a wave without output channels (or a 1x1 layer: two groups per chunk) stages in one go
@@ -738,269 +1054,8 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         }
     }
 
-    // ---- epilogue ----
-    if (!nvalid) return;
-    if constexpr (C::ABL & 1) {
-        float keep = 0.f;
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) keep += acc[t][r];
-        if (keep == 123.456f) static_cast<float*>(p.out)[0] = keep;
-        return;
-    }
-    const int n = ntile * 32 + li;
-    const bool nok = n < p.Cout;
-    if constexpr (C::SPLIT) {
-        // float32 out, straight from the accumulator layout (lane = channel): one dword per lane and register, 128 B per half
-        // wave and pixel -- full cache lines, no cross-lane transposes, no per-store address arithmetic (scalar offset per
-        // register, lane offset fixed), GroupNorm sums per lane = per channel.  (The 4 x 4 quad-transposed form below cost
-        // ~43 vector instructions per 16-byte store, 8 of them quarter-rate integer multiplies for the flat address.)
-        constexpr int ROWS = (MT * 32) >> C::LOGTW;
-        const bool full = oy0w + ROWS <= p.Hout && ox0 + C::TW <= p.Wout;          // wave-uniform
-        // (phase launches: output pixel (y, x) lands at (os y + ody, os x + odx) of the os-times larger tensor; os = 1 otherwise)
-        const unsigned os = (unsigned)p.ostep, WoutF = (unsigned)p.Wout * os;
-        const size_t first = (((size_t)b * p.Hout * os + (size_t)oy0w * os + p.ody) * WoutF + (size_t)ox0 * os + p.odx) * p.out_ld;
-        const size_t total = (size_t)p.B * p.Hout * os * WoutF * p.out_ld;
-        const size_t left = first < total ? (total - first) * 4 : 1;              // (tile rows wholly past the image: a resource no dword fits into)
-        constexpr unsigned kDrop = 0x80000000u;                                    // beyond any resource: the store is dropped
-        const __amdgpu_buffer_rsrc_t ors = buf_rsrc(static_cast<float*>(p.out) + (first < total ? first : 0), left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)left);
-        const unsigned vbase = nok ? ((unsigned)(4 * lh) * os * (unsigned)p.out_ld + (unsigned)n) * 4u : kDrop;
-        float un = asc.un;
-        if (asc.late && (p.residual || !bias_late)) {   // (rare: see ActScale) outputs first, then the additive terms at their own scale
-            add_terms(std::false_type{}, un, 1.f);   // (lanes without an output channel keep raw accumulators: never stored)
-            un = 1.f;
-        }
-        float addv = 0.f;                            // bias + temb of this lane's channel, added by the store loop's FMA
-        if (bias_late && nok) {
-            addv = p.bias ? p.bias[n] : 0.f;
-            if (p.temb) addv += p.temb[(size_t)b * p.temb_ld + n];
-        }
-        // (the sums variant also serves amax_out: a caller that wants only one of them pays for both)
-        const bool want_stats = (p.stats || p.amax_out) && !(C::ABL & 32);
-        double s1 = 0, s2 = 0;
-        float am = 0.f;
-        auto direct = [&](auto full_, auto has_stats) __attribute__((always_inline)) {
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int mb = t * 32 + 8 * (r >> 2) + (r & 3);
-                    const int row = mb >> C::LOGTW, col = mb & (C::TW - 1);
-                    const unsigned soff = ((unsigned)row * os * WoutF + (unsigned)col * os) * (unsigned)p.out_ld * 4u;
-                    const float x = fmaf(acc[t][r], un, addv);
-                    bool ok = true;
-                    if constexpr (!decltype(full_)::value) ok = oy0w + row < p.Hout && ox0 + col + 4 * lh < p.Wout;
-                    if constexpr (decltype(has_stats)::value) {
-                        const float xs = ok ? x : 0.f;
-                        const double d = (double)xs;
-                        s1 += d;
-                        s2 = fma(d, d, s2);
-                        am = fmaxf(am, fabsf(xs));                      // (NaN skipped, Inf kept)
-                    }
-                    buf_store1(ors, ok ? vbase : kDrop, soff, x);       // (last use of x: the tie in buf_store1 then costs no copy)
-                }
-        };
-        using T_ = std::true_type;
-        using F_ = std::false_type;
-        if (full) { if (want_stats) direct(T_{}, T_{}); else direct(T_{}, F_{}); }
-        else      { if (want_stats) direct(F_{}, T_{}); else direct(F_{}, F_{}); }
-        stamp(12);
-        if constexpr (C::WS && (C::ABL & 512) != 0) {
-            if (lane == 0) reinterpret_cast<unsigned long long*>(p.stats)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 16 + 15] = bar_ticks;
-        }
-        if (p.stats && !(C::ABL & 32)) {
-            s1 += __shfl_xor(s1, 32);                  // the two lane halves hold different pixels of the same channel
-            s2 += __shfl_xor(s2, 32);
-            if (lh == 0 && nok) {
-                const int slot = p.slot_base + (ty * p.tiles_x + tx) * p.stats_wm + (WM == 2 ? wm : 0);
-                const int nslots = p.nslots_total ? p.nslots_total : p.tiles_y * p.tiles_x * p.stats_wm;
-                double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + n) * 2;
-                o[0] = s1;
-                o[1] = s2;
-                if (WM == 1 && p.stats_wm == 2) {      // a 1 x 4 block of a layer whose LAST block runs 2 x 2: second slot = 0
-                    o[(size_t)p.Cout * 2] = 0.0;
-                    o[(size_t)p.Cout * 2 + 1] = 0.0;
-                }
-            }
-        }
-        if (p.amax_out && !(C::ABL & 32)) {
-            if (!nok) am = 0.f;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) am = fmaxf(am, __shfl_xor(am, off));
-            if (lane == 0) amax_publish(p.amax_out, b, (bx0 * 4 + wv) * 5 + by, am);
-        }
-        return;
-    }
-    if constexpr (kAccInit) {
-        // 16-bit out from the accumulator layout: lanes (2c, 2c+1) exchange one value per register pair (r, r+1 = the next
-        // pixel of the row), so the even lane stores channels (2c, 2c+1) of pixel r and the odd lane those of pixel r+1 --
-        // one packed dword per lane, 64 B per pixel and half wave, scalar offset per pair, GroupNorm sums per lane = channel
-        // (from the float32 accumulators, before rounding).  5 vector instructions per pair + the sums, where the
-        // quad-transposed form below cost ~30 per 8-byte store.
-        if (!p.out_f32 && !(p.Cout & 1)) {
-            constexpr int ROWS = (MT * 32) >> C::LOGTW;
-            const bool full = oy0w + ROWS <= p.Hout && ox0 + C::TW <= p.Wout;      // wave-uniform
-            const size_t first = (((size_t)b * p.Hout + oy0w) * p.Wout + ox0) * p.out_ld;
-            const size_t total = (size_t)p.B * p.Hout * p.Wout * p.out_ld;
-            const size_t left = first < total ? (total - first) * 2 : 1;          // (tile rows wholly past the image: a resource no dword fits into)
-            constexpr unsigned kDrop = 0x80000000u;
-            const __amdgpu_buffer_rsrc_t ors = buf_rsrc(static_cast<H*>(p.out) + (first < total ? first : 0), left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)left);
-            const int odd = li & 1;
-            const unsigned vbase = nok ? ((unsigned)(4 * lh + odd) * (unsigned)p.out_ld + (unsigned)(n - odd)) * 2u : kDrop;
-            const unsigned rot = odd ? 16u : 0u;
-            const bool want_stats = p.stats && !(C::ABL & 32);
-            double s1 = 0, s2 = 0;
-            auto direct = [&](auto full_, auto has_stats) __attribute__((always_inline)) {
-#pragma unroll
-                for (int t = 0; t < MT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const int mb = t * 32 + 8 * (r >> 2) + (r & 3);
-                        const int row = mb >> C::LOGTW, col = mb & (C::TW - 1);
-                        const unsigned soff = ((unsigned)row * (unsigned)p.Wout + (unsigned)col) * (unsigned)p.out_ld * 2u;
-                        const float x0 = acc[t][r], x1 = acc[t][r + 1];
-                        bool ok0 = true, ok1 = true;
-                        if constexpr (!decltype(full_)::value) {
-                            const bool rok = oy0w + row < p.Hout;
-                            ok0 = rok && ox0 + col + 4 * lh < p.Wout;
-                            ok1 = rok && ox0 + col + 4 * lh + 1 < p.Wout;
-                        }
-                        if constexpr (decltype(has_stats)::value) {
-                            const double d0 = ok0 ? (double)x0 : 0.0, d1 = ok1 ? (double)x1 : 0.0;
-                            s1 += d0;
-                            s2 = fma(d0, d0, s2);
-                            s1 += d1;
-                            s2 = fma(d1, d1, s2);
-                        }
-                        const float got = quad_xor1(odd ? x0 : x1);          // the neighbour lane's value for MY pixel
-                        const float keep = odd ? x1 : x0;
-                        using h2 = __attribute__((ext_vector_type(2))) H;
-                        const unsigned pk = __builtin_bit_cast(unsigned, h2{(H)keep, (H)got});      // even lane: (n, n+1)
-                        buf_store1(ors, (odd ? ok1 : ok0) ? vbase : kDrop, soff, __builtin_amdgcn_alignbit(pk, pk, rot));   // odd: (n-1, n)
-                    }
-            };
-            using T_ = std::true_type;
-            using F_ = std::false_type;
-            if (full) { if (want_stats) direct(T_{}, T_{}); else direct(T_{}, F_{}); }
-            else      { if (want_stats) direct(F_{}, T_{}); else direct(F_{}, F_{}); }
-            if (want_stats) {
-                s1 += __shfl_xor(s1, 32);
-                s2 += __shfl_xor(s2, 32);
-                if (lh == 0 && nok) {
-                    const int slot = (ty * p.tiles_x + tx) * p.stats_wm + (WM == 2 ? wm : 0);
-                    const int nslots = p.tiles_y * p.tiles_x * p.stats_wm;
-                    double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + n) * 2;
-                    o[0] = s1;
-                    o[1] = s2;
-                    if (WM == 1 && p.stats_wm == 2) {
-                        o[(size_t)p.Cout * 2] = 0.0;
-                        o[(size_t)p.Cout * 2 + 1] = 0.0;
-                    }
-                }
-            }
-            return;
-        }
-    }
-    float add = 0.f;
-    if (nok) {
-        add = p.bias ? p.bias[n] : 0.f;
-        if (p.temb) add += p.temb[(size_t)b * p.temb_ld + n];
-    }
-    // 16-bit storage -- packed epilogue: 4x4 blocks (4 consecutive pixels x the quad's 4 channels) are transposed across lane quads in
-    // registers, so every lane stores / loads 4 consecutive channels of ONE pixel (8 B fp16, 16 B fp32) -- 4x fewer,
-    // 4x wider memory instructions than the accumulator layout allows.  GroupNorm sums are reduced in that layout.
-    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    auto epilogue = [&](auto has_res, auto has_stats, auto out32) __attribute__((always_inline)) {
-        using res_t = h4;
-        using rel_t = H;
-        res_t rv[MT][4];
-        if constexpr (decltype(has_res)::value) {      // one batch of 8/16-byte loads (a load in the last chunk instead
-#pragma unroll                                          // would queue the weight ring behind HBM misses: vmcnt is in-order)
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int m = t * 32 + 8 * k + q4 + 4 * lh;
-                    const int oy = min(oy0w + (m >> C::LOGTW), p.Hout - 1), ox = min(ox0 + (m & (C::TW - 1)), p.Wout - 1);
-                    rv[t][k] = *reinterpret_cast<const res_t*>(static_cast<const rel_t*>(p.residual) +
-                                                               (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + (quad_ok ? cq : 0));
-                }
-        }
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float x[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) x[c] = kAccInit ? acc[t][4 * k + c] : acc[t][4 * k + c] + add;
-                quad_transpose(x, q4);                        // now: pixel 8k + q4 (+4 lh) of tile t, channels cq..cq+3
-                const int m = t * 32 + 8 * k + q4 + 4 * lh;
-                const int oy = oy0w + (m >> C::LOGTW), ox = ox0 + (m & (C::TW - 1));
-                if (quad_ok && oy < p.Hout && ox < p.Wout) {
-                    const size_t pix = ((size_t)b * p.Hout + oy) * p.Wout + ox;
-                    if constexpr (decltype(has_res)::value) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) x[c] += (float)rv[t][k][c];
-                    }
-                    if constexpr (decltype(out32)::value) {
-                        *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + pix * p.out_ld + cq) = f32x4{x[0], x[1], x[2], x[3]};
-                    } else {
-                        *reinterpret_cast<h4*>(static_cast<H*>(p.out) + pix * p.out_ld + cq) =
-                            h4{(H)x[0], (H)x[1], (H)x[2], (H)x[3]};
-                    }
-                    if constexpr (decltype(has_stats)::value) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const double d = (double)x[c];
-                            s1[c] += d;
-                            s2[c] = fma(d, d, s2[c]);
-                        }
-                    }
-                }
-            }
-        }
-    };
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-    if constexpr (kAccInit) {   // 16-bit storage, bias / temb / residual already in the accumulators
-        if (p.out_f32) epilogue(F_{}, F_{}, T_{});
-        else if (p.stats) epilogue(F_{}, T_{}, F_{});
-        else epilogue(F_{}, F_{}, F_{});
-    } else if (p.out_f32) {
-        if (p.residual) epilogue(T_{}, F_{}, T_{}); else epilogue(F_{}, F_{}, T_{});
-    } else if (p.residual) {
-        if (p.stats) epilogue(T_{}, T_{}, F_{}); else epilogue(T_{}, F_{}, F_{});
-    } else {
-        if (p.stats) epilogue(F_{}, T_{}, F_{}); else epilogue(F_{}, F_{}, F_{});
-    }
-    if (p.stats) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {      // the quad's 4 lanes and the two lane halves hold different pixels
-            s1[c] += __shfl_xor(s1[c], 1);
-            s2[c] += __shfl_xor(s2[c], 1);
-            s1[c] += __shfl_xor(s1[c], 2);
-            s2[c] += __shfl_xor(s2[c], 2);
-            s1[c] += __shfl_xor(s1[c], 32);
-            s2[c] += __shfl_xor(s2[c], 32);
-        }
-        if (lh == 0 && q4 == 0 && quad_ok) {
-            // p.stats_wm slots per tile: a layer with a 2 x 2 last block has two (its 1 x 4 blocks fill the first and zero the second)
-            const int slot = (ty * p.tiles_x + tx) * p.stats_wm + (WM == 2 ? wm : 0);
-            const int nslots = p.tiles_y * p.tiles_x * p.stats_wm;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (cq + c < p.Cout) {
-                    double* o = p.stats + (((size_t)b * nslots + slot) * p.Cout + cq + c) * 2;
-                    o[0] = s1[c];
-                    o[1] = s2[c];
-                    if (WM == 1 && p.stats_wm == 2) {
-                        o[(size_t)p.Cout * 2] = 0.0;
-                        o[(size_t)p.Cout * 2 + 1] = 0.0;
-                    }
-                }
-            }
-        }
-    }
+    if (nvalid) run_epilogue();
+    }      // tiles of the sequence
 }
 
 template <class C, int STG>
@@ -1036,8 +1091,8 @@ __global__ __launch_bounds__(512, 4) void conv16_ws_kernel(const Conv16Params p)
     conv16_body<C, STG, 1>(p, lds_all, bx, by);
 }
 
-#ifdef CDX_TUNING
 #include <stdlib.h>
+#ifdef CDX_TUNING
 // tuning build only: CDX_NO_WS=1 routes the wave-specialised launches to the 4-wave kernel of the same configuration (same-box
 // A/B of whole bench runs: tools/session/gpu_r3h.sh)
 inline bool ws_disabled() {
@@ -1049,12 +1104,26 @@ inline bool ws_disabled() {
 template <class C>
 inline int conv16_launch(const Conv16Params& p, hipStream_t stream);
 
-template <class C>
-inline int conv16_ws_launch(const Conv16Params& p, hipStream_t stream) {
+// Tiles per workgroup sequence of a wave-specialised launch (Conv16Params::seq): as long as the launch still has several
+// workgroups per resident slot (2 per CU x 256 CUs) to even out the tail, up to 4 tiles share one prologue.
+inline int conv16_ws_seq(int ntiles, int nblocks_y) {
 #ifdef CDX_TUNING
-    if (ws_disabled()) return conv16_launch<Conv16Cfg<C::KS, C::STRIDE, C::LOGTW, C::MT, C::PF, C::ABL, C::SPLIT, C::DB, C::BF, 0>>(p, stream);
+    static const int forced = [] { const char* e = getenv("CDX_SEQ"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced;
 #endif
-    dim3 grid(p.tiles_x * p.tiles_y * p.B, ceil_div(p.Cout, C::BN));
+    const long wgs = (long)ntiles * nblocks_y;
+    return wgs >= 4 * 2048 ? 4 : wgs >= 2 * 2048 ? 2 : 1;
+}
+
+template <class C>
+inline int conv16_ws_launch(const Conv16Params& p0, hipStream_t stream) {
+#ifdef CDX_TUNING
+    if (ws_disabled()) return conv16_launch<Conv16Cfg<C::KS, C::STRIDE, C::LOGTW, C::MT, C::PF, C::ABL, C::SPLIT, C::DB, C::BF, 0>>(p0, stream);
+#endif
+    Conv16Params p = p0;
+    const int ntiles = p.tiles_x * p.tiles_y * p.B;
+    if (p.seq <= 0) p.seq = conv16_ws_seq(ntiles, ceil_div(p.Cout, C::BN));
+    dim3 grid(ceil_div(ntiles, p.seq), ceil_div(p.Cout, C::BN));
     switch (p.gn ? (p.silu ? 2 : 1) : (p.silu ? 3 : 0)) {
         case 0: hipLaunchKernelGGL((conv16_ws_kernel<C, 0>), grid, dim3(512), 0, stream, p); break;
         case 1: hipLaunchKernelGGL((conv16_ws_kernel<C, 1>), grid, dim3(512), 0, stream, p); break;

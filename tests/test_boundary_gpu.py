@@ -131,3 +131,78 @@ def test_16bit_tiles_lower_than_a_tile(cdx_mod, bf16, H, geom, co, fused):
     close(nchw(out.float()), want, tol, f"{'bf16' if bf16 else 'fp16'} H={H} {geom} cout={co}")
     if fused and co % 4 == 0:
         assert not torch.isnan(r[1]).any(), "a GroupNorm-sum slot was left unwritten"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Tile SEQUENCES of the wave-specialised kernels (Conv16Params::seq): a workgroup walks 2 or 4 consecutive tiles, the producer
+# waves staging the next tile's first chunks under the current tile's last MFMAs.  The launcher picks seq from the number of
+# workgroups (>= 4096: 2, >= 8192: 4), so only large launches take that path: these shapes cross both thresholds, with tile counts
+# that are NOT multiples of seq (a shorter last sequence), sequences that cross image boundaries (per-image activation exponent,
+# per-image buffer resources), odd chunk counts (the LDS image parity flips from tile to tile) and ragged tile rows / columns.
+SEQ_CASES = [   # (B, H, W, cin, cout, fused)                          tiles x channel blocks -> seq
+    (9, 248, 272, 32, 128, False),     # 4743 tiles (odd), 1 chunk                         -> 2, last workgroup: one tile
+    (9, 248, 272, 96, 128, True),      # ... 3 chunks (odd), GroupNorm + SiLU + temb + residual + sums
+    (17, 256, 250, 64, 128, True),     # 8704 tiles, ragged columns, 2 chunks                -> 4
+    (5, 250, 256, 64, 256, False),     # 2560 tiles x 2 channel blocks = 5120                -> 2
+    (3, 500, 500, 32, 192, True),      # 6048 tiles x (128 + 64-channel tail block: 2 x 2 wave layout) -> 4, ragged in x and y
+]
+
+
+@pytest.mark.parametrize("case", SEQ_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_tile_sequences_of_the_wave_specialised_kernels(cdx_mod, case, dtype):
+    ops = cdx_mod.ops
+    B, H, W, ci, co, fused = case
+    torch.manual_seed(7)
+    x = rnd(B, ci, H, W, seed=300) * 1.5 + 0.4
+    for b in range(B):                       # images at different scales: the un-normalised launch takes a per-image exponent
+        x[b] *= 10.0 ** ((b % 5) - 2)
+    w = rnd(co, ci, 3, 3, seed=301, scale=1.0 / math.sqrt(ci * 9))
+    bias = rnd(co, seed=302)
+    gamma, beta = 1 + 0.2 * rnd(ci, seed=303), 0.3 * rnd(ci, seed=304)
+    temb, res = rnd(B, co + 2, seed=305), rnd(B, co, H, W, seed=306)
+    half = dtype == "fp16"
+    rd = (lambda t: t.half().float()) if half else (lambda t: t)
+    h = rd(x).double()
+    if fused:
+        h = F.silu(F.group_norm(h, 32, gamma.double(), beta.double(), eps=1e-5))
+        if half:
+            h = h.half().double()
+    torch.set_num_threads(16)
+    want = F.conv2d(h, rd(w).double(), bias.double(), padding=1)
+    if fused:
+        want = want + temb[:, 1:1 + co].double()[:, :, None, None] + rd(res).double()
+    dt = torch.float16 if half else torch.float32
+    big, out = guarded((B, H, W, co), dt)
+    out.fill_(float("nan"))
+    if half:
+        pc = ops.PackedConv16(w.numpy(), bias.numpy(), ci)
+        xd = nhwc(x).half()
+        kw = dict(out=out)
+        if fused:
+            sc, sh = ops.gn_stats(xd.float().contiguous(), None, gamma.cuda(), beta.cuda(), 32)
+            kw.update(gn=(sc, sh), silu=True, temb=temb.cuda(), temb_off=1, residual=nhwc(res).half(), want_stats=True)
+        r = ops.conv16(pc, xd, **kw)
+        tol = 4e-3 if fused else 1e-3
+    else:
+        pc = ops.PackedConv(w.numpy(), bias.numpy(), ci)
+        xd = nhwc(x)
+        kw = dict(out=out)
+        if fused:
+            kw.update(gn_affine=(gamma.cuda(), beta.cuda(), 32), silu=True, temb=temb.cuda(), temb_off=1, residual=nhwc(res), want_stats=True)
+        r = ops.conv(pc, xd, **kw)
+        tol = 3e-6
+    torch.cuda.synchronize()
+    assert (big[out.numel():] == torch.tensor(SENTINEL).to(dt).item()).all(), "wrote past the output tensor"
+    got = nchw(out.float())
+    for b in range(B):                       # each image against ITS output scale (the scales differ by 1e4 when un-normalised)
+        close(got[b], want[b], tol, f"{dtype} image {b} of {case}")
+    if fused:
+        st = r[1]
+        assert not torch.isnan(st).any(), "a GroupNorm-sum slot was left unwritten"
+        close(st[..., 0].sum(1).cpu(), got.double().sum((2, 3)), 2e-3 if half else 1e-5, "GroupNorm sums")
+    # determinism: the same launch again gives the same bits
+    out2 = torch.empty_like(out)
+    kw["out"] = out2
+    (ops.conv16 if half else ops.conv)(pc, xd, **kw)
+    assert torch.equal(out, out2)

@@ -18,30 +18,45 @@ from cdx import ops, _abi
 ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="16,256,256,128,0,128")
 ap.add_argument("--tile", type=int, default=108)
+ap.add_argument("--fp16", action="store_true", help="the 16-bit storage tile (cdx_conv_f16, tuning flag bits 8..11 = 10) instead of the float32 split tile")
 a = ap.parse_args()
 B, H, W, c0, c1, co = map(int, a.shape.split(","))
 g = torch.Generator(device="cuda").manual_seed(0)
-x0 = torch.randn(B, H, W, c0, device="cuda", generator=g)
-x1 = torch.randn(B, H, W, c1, device="cuda", generator=g) if c1 else None
-w = (np.random.default_rng(0).standard_normal((co, c0 + c1, 3, 3)) / math.sqrt((c0 + c1) * 9)).astype(np.float32)
-pc = ops.PackedConv(w, np.zeros(co, np.float32), c0, c1)
-out = torch.empty(B, H, W, co, device="cuda")
-gamma, beta = torch.ones(c0 + c1, device="cuda"), torch.zeros(c0 + c1, device="cuda")
-kw = dict(gn=ops.gn_stats(x0, x1, gamma, beta, 32, act_exp="auto"), silu=True, temb=torch.randn(B, co, device="cuda"),
-          residual=torch.randn(B, H, W, co, device="cuda"))
-args = ops.conv_args(pc, x0, x1, out, **kw)
+L = _abi.lib()
+st = torch.cuda.current_stream().cuda_stream
 nblocks = B * ((H + 7) // 8) * ((W + 15) // 16) * ((co + 127) // 128)
 rows = 2 * nblocks * 4
 big = torch.zeros(max(rows * 16, 1 << 20), dtype=torch.float64, device="cuda")
-_keep = ops.conv_stats_buffer(args, "cuda")      # sets stats_slots
-args.stats_out = big.data_ptr()
-L = _abi.lib()
-st = torch.cuda.current_stream().cuda_stream
+w = (np.random.default_rng(0).standard_normal((co, c0 + c1, 3, 3)) / math.sqrt((c0 + c1) * 9)).astype(np.float32)
+if a.fp16:
+    assert c1 == 0
+    x0 = torch.randn(B, H, W, c0, device="cuda", generator=g).half()
+    pc = ops.PackedConv16(w, np.zeros(co, np.float32), c0, 0)
+    out = torch.empty(B, H, W, co, device="cuda", dtype=torch.float16)
+    sc, sh = torch.ones(B, c0, device="cuda"), torch.zeros(B, c0, device="cuda")
+    args = ops.conv16_args(pc, x0, None, out, gn=(sc, sh), silu=True, temb=torch.randn(B, co, device="cuda"),
+                           residual=torch.randn(B, H, W, co, device="cuda").half())
+    args.flags |= 10 << 8                            # tuning flag bits 8..11: the stamping variant of the 16-bit tile
+    _keep = ops.conv16_stats_buffer(args, "cuda")
+    args.stats_out = big.data_ptr()
+    launch = lambda: L.cdx_conv_f16(ctypes.byref(args), None, 0, st)      # noqa: E731
+else:
+    x0 = torch.randn(B, H, W, c0, device="cuda", generator=g)
+    x1 = torch.randn(B, H, W, c1, device="cuda", generator=g) if c1 else None
+    pc = ops.PackedConv(w, np.zeros(co, np.float32), c0, c1)
+    out = torch.empty(B, H, W, co, device="cuda")
+    gamma, beta = torch.ones(c0 + c1, device="cuda"), torch.zeros(c0 + c1, device="cuda")
+    kw = dict(gn=ops.gn_stats(x0, x1, gamma, beta, 32, act_exp="auto"), silu=True, temb=torch.randn(B, co, device="cuda"),
+              residual=torch.randn(B, H, W, co, device="cuda"))
+    args = ops.conv_args(pc, x0, x1, out, **kw)
+    _keep = ops.conv_stats_buffer(args, "cuda")      # sets stats_slots
+    args.stats_out = big.data_ptr()
+    launch = lambda: L.cdx_conv_f32_tile(ctypes.byref(args), a.tile, None, 0, st)      # noqa: E731
 for _ in range(3):
     big.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    rc = L.cdx_conv_f32_tile(ctypes.byref(args), a.tile, None, 0, st)
+    rc = launch()
     assert rc == 0, rc
     e1.record()
     torch.cuda.synchronize()
