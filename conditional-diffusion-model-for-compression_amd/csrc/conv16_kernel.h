@@ -321,7 +321,10 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     int soff[NPASS];                                  // pixel index inside image b
     unsigned vmask = 0;
     int cur_src = -1;                                 // source the halo loads are bound to (-1: rebind at the next issue_loads)
-    auto set_tile = [&](int T) __attribute__((always_inline)) {
+    // (scalar part: image, tile row / column, origins, activation scale -- wave-uniform; the MFMA waves re-derive it from an
+    // OPAQUE copy of the tile index wherever they need it (tile start, epilogue) instead of carrying ~20 scalar registers through
+    // the MFMA loop: the kernel sits at the scalar-register limit, and what does not fit is spilled into vector registers)
+    auto set_geo = [&](int T) __attribute__((always_inline)) {
         tile_id = T;
         tx = T % p.tiles_x;
         const int r = T / p.tiles_x;
@@ -333,6 +336,9 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         iy0 = oy0 * C::STRIDE - (C::KS == 2 ? p.pady : C::PAD);
         ix0 = ox0 * C::STRIDE - (C::KS == 2 ? p.padx : C::PAD);
         asc = act_scale_of<C::SPLIT != 0, kGN>(p, b);
+    };
+    auto set_tile = [&](int T) __attribute__((always_inline)) {
+        set_geo(T);
         vmask = 0;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
@@ -600,9 +606,14 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     constexpr int G0 = GPC > NU + 1 ? GPC - NU - 1 : 0;
     static_assert(NU + 1 <= GPC || GPC <= 2 || !C::DB, "staging units must fit in the chunk's groups (1x1: done after the groups)");
     // ---- epilogue of ONE tile (a lambda: the tile loop below runs it once per tile of the workgroup's sequence) ----
-    auto run_epilogue = [&]() __attribute__((always_inline)) {
+    auto run_epilogue = [&](int qi) __attribute__((always_inline)) {
     // ---- epilogue ----
     if (!nvalid) return;
+    if constexpr (C::WS) {      // (see set_geo: nothing of the tile's geometry lives through the MFMA loop)
+        int T = T0 + qi;
+        asm volatile("" : "+s"(T));
+        set_geo(T);
+    }
     // The lane's coordinates are re-derived from an OPAQUE copy of the lane id: the epilogue now sits inside the tile loop, and
     // everything in it that does not depend on the tile (store offsets, channel indices, masks) would otherwise be hoisted in
     // front of that loop and held in registers across the MFMA loop -- which has none to spare (measured: 80 - 1000 spilled
@@ -883,7 +894,9 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     h8 a[MT], al[MT];
     // ---- the workgroup's tiles, one after the other (4-wave kernels: one) ----
     for (int qi = 0; qi < nseq; ++qi) {
-    if (qi > 0) set_tile(T0 + qi);
+    if (qi > 0) {
+        if constexpr (C::WS) set_geo(T0 + qi); else set_tile(T0 + qi);
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -1054,7 +1067,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         }
     }
 
-    if (nvalid) run_epilogue();
+    if (nvalid) run_epilogue(qi);
     }      // tiles of the sequence
 }
 
