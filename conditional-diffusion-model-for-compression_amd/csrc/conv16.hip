@@ -83,8 +83,7 @@ int conv16_dispatch(int ks, int stride, int logtw, int mt, bool bf, const Conv16
             case 6: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 2, 0, 1, 0, 1>>(p, stream);      // ... producers stage only the first chunk (the MFMA waves' bound)
             case 3: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 1, 0, 1, 0, 1>>(p, stream);      // ... no epilogue
             case 2: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 3, 0, 1, 0, 1>>(p, stream);      // ... neither
-            case 10: { Conv16Params q = p; q.seq = 1; return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 544, 0, 1, 0, 1>>(q, stream); }
-            case 11: case 12: case 13: { Conv16Params q = p; q.seq = 1 << (p.abl - 11); return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 0, 0, 1, 0, 1>>(q, stream); }   // ... 1 / 2 / 4 tiles per workgroup sequence
+            case 10: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 544, 0, 1, 0, 1>>(p, stream);   // ... per-wave stamps / barrier accounting instead of GroupNorm sums (tools/ws_stamps.py --fp16)
             case 9: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 8192, 0, 1, 0, 1>>(p, stream);   // ... XCD-contiguous workgroup order (measured, not shipped)
             case 8: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 4096, 0, 1, 0, 1>>(p, stream);   // ... operand reads NOT software-pipelined (round 3's MFMA waves)
             default: return CDX_ENOTSUP;
@@ -190,7 +189,6 @@ extern "C" int cdx_conv_f16(const cdx_conv_f16_args* a, void*, size_t, cdx_strea
     p.out = a->out; p.out_f32 = a->out_is_f32 ? 1 : 0; p.out_ld = a->out_ld; p.stats = a->stats_out;
     p.stats_wm = conv16_tail_2x2(a->cout, f16_mt(a)) ? 2 : 1;
     p.ostep = 1; p.ody = p.odx = 0; p.pady = p.padx = a->ksize / 2; p.slot_base = 0; p.nslots_total = 0;
-    p.seq = 0;            // wave-specialised launches: tiles per workgroup chosen by conv16_ws_launch
     p.act_exp = 0;
     p.amax[0] = p.amax[1] = nullptr;
     p.amax_out = nullptr;

@@ -89,11 +89,6 @@ struct Conv16Params {
     // launch is stored at (ostep y + ody, ostep x + odx) of the full-resolution tensor, the halo starts pady / padx pixels up / left
     // of the tile, and the launch's GroupNorm-sum slots start at slot_base of nslots_total.  Plain launches: 1, 0, 0, PAD, PAD, 0, 0.
     int ostep, ody, odx, pady, padx, slot_base, nslots_total;
-    // Wave-specialised kernels: a workgroup walks a SEQUENCE of `seq` consecutive spatial tiles (grid.x = ceil(tiles / seq)): the
-    // producer waves load and stage the next tile's first chunks under the current tile's last MFMAs, so only the first tile of a
-    // sequence waits for its halo (tools/ws_stamps.py: that wait was 18 % of an MFMA wave's life in the float32 tile, 30 % in the
-    // 16-bit tile).  0 = let the launcher choose; the 4-wave kernels ignore it (one tile per workgroup).
-    int seq;
     int act_exp;
     const unsigned* amax[2]; // [B][CDX_AMAX_WORDS] float32 bit patterns (max over the words = max |x| of the image) per source, or null
     unsigned* amax_out;      // [B][CDX_AMAX_WORDS] or null: atomic max of one word with the bit pattern of the wave's max |out|
@@ -249,13 +244,14 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wv % WN, wm = wv / WN;
 
-    // The workgroup's tile sequence: tiles T0 .. T0 + nseq - 1 of the launch's tiles_x * tiles_y * B spatial tiles (4-wave kernels:
-    // one tile).  Everything below that depends on the tile is (re)computed by set_tile().
-    const int ntiles_all = p.tiles_x * p.tiles_y * p.B;
-    const int seq = C::WS ? (p.seq > 0 ? p.seq : 1) : 1;
-    const int T0 = bx * seq;
-    const int nseq = C::WS ? (ntiles_all - T0 < seq ? ntiles_all - T0 : seq) : 1;
-    int tile_id, tx, ty, b, oy0, ox0, oy0w, iy0, ix0;
+    const int bx0 = bx;
+    const int tx = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int b = bx / p.tiles_y;
+    const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+    const int oy0w = oy0 + ((wm * MT * 32) >> C::LOGTW);           // first output row of THIS wave's M-tiles
+    const int iy0 = oy0 * C::STRIDE - (C::KS == 2 ? p.pady : C::PAD), ix0 = ox0 * C::STRIDE - (C::KS == 2 ? p.padx : C::PAD);
     // ABL & 512 (diagnostic build): s_memtime stamps per wave at the phase boundaries, 16 per wave, into the buffer behind
     // p.stats (which then holds no sums): 0 entry, 1 first loads issued, 2 first chunk staged (barrier passed), 3 + c chunk c
     // done (c < 8), 12 stores issued, 13 HW_ID, 14 XCC_ID  (digest: tools/conv_bench.py --stamps)
@@ -314,44 +310,21 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         }
     }
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
-    ActScale asc;
+    const ActScale asc = act_scale_of<C::SPLIT != 0, kGN>(p, b);
 
     // ---- loader: thread -> (pixel slot pl of 64, channel octet q of 4) ----
     const int q = tid & 3, pl = tid >> 2;
     int soff[NPASS];                                  // pixel index inside image b
     unsigned vmask = 0;
-    int cur_src = -1;                                 // source the halo loads are bound to (-1: rebind at the next issue_loads)
-    // (scalar part: image, tile row / column, origins, activation scale -- wave-uniform; the MFMA waves re-derive it from an
-    // OPAQUE copy of the tile index wherever they need it (tile start, epilogue) instead of carrying ~20 scalar registers through
-    // the MFMA loop: the kernel sits at the scalar-register limit, and what does not fit is spilled into vector registers)
-    auto set_geo = [&](int T) __attribute__((always_inline)) {
-        tile_id = T;
-        tx = T % p.tiles_x;
-        const int r = T / p.tiles_x;
-        ty = r % p.tiles_y;
-        b = r / p.tiles_y;
-        oy0 = ty * C::TH;
-        ox0 = tx * C::TW;
-        oy0w = oy0 + ((wm * MT * 32) >> C::LOGTW);           // first output row of THIS wave's M-tiles
-        iy0 = oy0 * C::STRIDE - (C::KS == 2 ? p.pady : C::PAD);
-        ix0 = ox0 * C::STRIDE - (C::KS == 2 ? p.padx : C::PAD);
-        asc = act_scale_of<C::SPLIT != 0, kGN>(p, b);
-    };
-    auto set_tile = [&](int T) __attribute__((always_inline)) {
-        set_geo(T);
-        vmask = 0;
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            const int hp = i * 64 + pl;
-            const int hy = hp / C::HW, hx = hp - hy * C::HW;
-            const int iy = iy0 + hy, ix = ix0 + hx;
-            const bool ok = hp < C::NPIX && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-            soff[i] = ok ? (iy >> p.ups) * p.Win + (ix >> p.ups) : 0;
-            vmask |= ok ? (1u << i) : 0u;
-        }
-        cur_src = -1;                                 // (the buffer resource covers image b of the source)
-    };
-    set_tile(T0);
+    for (int i = 0; i < NPASS; ++i) {
+        const int hp = i * 64 + pl;
+        const int hy = hp / C::HW, hx = hp - hy * C::HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool ok = hp < C::NPIX && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+        soff[i] = ok ? (iy >> p.ups) * p.Win + (ix >> p.ups) : 0;
+        vmask |= ok ? (1u << i) : 0u;
+    }
     float pre[NPASS][8];
     f32x4 gsc[2], gsh[2];
     bool cvalid;
@@ -366,6 +339,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     // after the activation, so neither GroupNorm's shift nor NaN / Inf in the dummy can leak into the padding.
     unsigned voff[NPASS];
     __amdgpu_buffer_rsrc_t srs;
+    int cur_src = -1;
     const unsigned esz = (C::SPLIT || p.src_f32) ? 4u : 2u;
     auto bind_source = [&](int sidx) {
         const unsigned cs = (unsigned)p.csrc[sidx];
@@ -482,29 +456,18 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
 
     if constexpr (C::WS) {
         if (producer) {      // ---- producer waves: stage every chunk, one barrier per chunk in step with the MFMA waves ----
-            // The chunks of the workgroup's tile sequence form ONE flat sequence k = tile * nchunks + chunk, staged into image k & 1:
-            // while the MFMA waves work on k, chunk k + 1 is staged and the halo loads of k + 2 are issued -- across tile boundaries
-            // too, so the next tile's first chunk is in LDS when the MFMA waves leave the current tile's epilogue.  (Staging chunk k
-            // reads the tile state -- padding mask, activation scale -- that issue(k) set: program order is stage(k + 1), issue(k + 2).)
-            const int K = nseq * p.nchunks;
-            int kt = 0, kc = 0;                       // (tile in the sequence, chunk) of the NEXT issue
-            auto issue_next = [&]() __attribute__((always_inline)) {
-                if (kc == 0 && kt > 0) set_tile(T0 + kt);
-                issue_loads(kc);
-                if (++kc == p.nchunks) { kc = 0; ++kt; }
-            };
-            issue_next();
+            issue_loads(0);
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
-            if (K > 1 && !(C::ABL & 2)) issue_next();
+            if (p.nchunks > 1 && !(C::ABL & 2)) issue_loads(1);
             __syncthreads();
-            for (int k = 0; k < K; ++k) {
-                H* nxt = lds_all + ((k + 1) & 1) * C::LDS_HALVES;
-                if (k + 1 < K && !(C::ABL & 2)) {
+            for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+                H* nxt = lds_all + ((chunk + 1) & 1) * C::LDS_HALVES;
+                if (chunk + 1 < p.nchunks && !(C::ABL & 2)) {
                     const unsigned long long t0 = memtime();
 #pragma unroll
                     for (int i = 0; i < NPASS; ++i) write_pass(nxt, i);
-                    if (k + 2 < K) issue_next();
+                    if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
                     stage_ticks += memtime() - t0;
                 }
                 timed_barrier();
@@ -532,6 +495,10 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     auto wload = [&](unsigned half_off) { return __builtin_bit_cast(h8, buf_load4(wrs, wlane, half_off * 2u)); };
 
     f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     // bias + temb + residual enter through the accumulator init (SPLIT: scaled by 1/unscale, a power of two: exact), so the
     // residual tile is fetched under the first chunk's staging instead of standing between the last MFMA and the stores
     // (measured: the epilogue's residual loads were 6 % of the SPLIT kernel).  Accumulator layout of the 32x32 MFMA: lane =
@@ -554,9 +521,6 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
 #endif
     auto add_terms = [&](auto first_, float macc, float inv) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_)::value;
-        int lane_i = (int)(wlane >> 4);                       // (opaque, as in the epilogue: nothing of the NEXT tile's init may be
-        asm volatile("" : "+v"(lane_i));                      //  precomputed and carried through the current tile's MFMA loop)
-        const int li = lane_i & 31, lh = lane_i >> 5;
         const int n = ntile * 32 + li;
         if (!(nvalid && n < p.Cout)) return;
         float add = 0.f;
@@ -599,32 +563,183 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                 for (int r = 0; r < 16; ++r) acc[t][r] = FIRST ? add : fmaf(acc[t][r], macc, add);
         }
     };
-    h8 ring[PF][C::PLANES];
-
-    // staging schedule inside a chunk: passes at groups G0 .. G0+NPASS-1, the loads of the chunk after next right behind
-    constexpr int NU = UPP * NPASS;
-    constexpr int G0 = GPC > NU + 1 ? GPC - NU - 1 : 0;
-    static_assert(NU + 1 <= GPC || GPC <= 2 || !C::DB, "staging units must fit in the chunk's groups (1x1: done after the groups)");
-    // ---- epilogue of ONE tile (a lambda: the tile loop below runs it once per tile of the workgroup's sequence) ----
-    auto run_epilogue = [&](int qi) __attribute__((always_inline)) {
-    // ---- epilogue ----
-    if (!nvalid) return;
-    if constexpr (C::WS) {      // (see set_geo: nothing of the tile's geometry lives through the MFMA loop)
-        int T = T0 + qi;
-        asm volatile("" : "+s"(T));
-        set_geo(T);
+    if constexpr (kAccInit) {
+        if (!asc.late) add_terms(std::true_type{}, 1.f, asc.inv);
     }
-    // The lane's coordinates are re-derived from an OPAQUE copy of the lane id: the epilogue now sits inside the tile loop, and
-    // everything in it that does not depend on the tile (store offsets, channel indices, masks) would otherwise be hoisted in
-    // front of that loop and held in registers across the MFMA loop -- which has none to spare (measured: 80 - 1000 spilled
-    // dwords, some inside the chunk loop).  A handful of integer instructions per tile instead.
-    int lane_e = (int)(wlane >> 4);                           // (wlane = 16 lane is live across the loop anyway)
-    asm volatile("" : "+v"(lane_e));
-    const int li = lane_e & 31, lh = lane_e >> 5;
+
+    h8 ring[PF][C::PLANES];
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+#pragma unroll
+        for (int pl_ = 0; pl_ < C::PLANES; ++pl_) ring[j][pl_] = wload(j * GH + pl_ * 512);
+
     // packed-epilogue layout (see below)
     const int q4 = li & 3;
     const int cq = ntile * 32 + (li & ~3);                    // first of this quad's 4 channels
     const bool quad_ok = nvalid && cq < p.Cout;               // (cout is a multiple of 4 or the tail is zero-weighted)
+    // staging schedule inside a chunk: passes at groups G0 .. G0+NPASS-1, the loads of the chunk after next right behind
+    constexpr int NU = UPP * NPASS;
+    constexpr int G0 = GPC > NU + 1 ? GPC - NU - 1 : 0;
+    static_assert(NU + 1 <= GPC || GPC <= 2 || !C::DB, "staging units must fit in the chunk's groups (1x1: done after the groups)");
+    if constexpr (!C::WS) {
+        issue_loads(0);
+        stamp(1);
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
+        if (p.nchunks > 1 && !(C::ABL & 2)) issue_loads(1);
+    }
+    __syncthreads();
+    stamp(2);
+    h8 a[MT], al[MT];
+    if constexpr (C::ABL & 8) {                 // ablation: operands read once
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            a[t] = *reinterpret_cast<const h8*>(&lds_all[a_base + t * C::RPM * C::STRIDE * RSH]);
+            al[t] = *reinterpret_cast<const h8*>(&lds_all[a_base + t * C::RPM * C::STRIDE * RSH + 16]);
+        }
+    }
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const H* lds = lds_all + (C::DB ? (chunk & 1) * C::LDS_HALVES : 0);
+        H* nxt = lds_all + (C::DB ? ((chunk + 1) & 1) * C::LDS_HALVES : 0);
+        const bool more = chunk + 1 < p.nchunks && !(C::ABL & 2);
+        if (!C::WS && C::DB && (!nvalid || GPC <= 2)) {
+            // a wave without output channels (or a 1x1 layer: two groups per chunk) stages in one go
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < NPASS; ++i) write_pass(nxt, i);
+                if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
+            }
+        }
+        if (nvalid) {
+            const unsigned wc = (unsigned)chunk * (unsigned)(TAPS * 2 * GH);      // halves, scalar
+#pragma unroll
+            for (int g = 0; g < GPC; ++g) {
+                // Staging groups (g in [G0, G0 + NU), next chunk exists): the unit's four channel computations are placed
+                // BETWEEN quarters of the group's MFMAs, fenced by sched_barriers -- left alone the scheduler emits the unit's
+                // ~60 VALU instructions as one clump in front of the group's first MFMA (and sched_group_barrier pipelines
+                // did not move them).  A quarter = 3 MFMAs (96 matrix-pipe cycles) + ~14 VALU instructions.
+                constexpr int NM = MT * (C::SPLIT ? 3 : 1);                  // MFMAs per group
+                constexpr bool kInterleave = C::DB && GPC > 2 && NM >= 4 && !(C::ABL & 128);
+                // (compile-time: in the LAST chunk the unit restages stale registers into the idle image -- harmless, and it
+                // keeps the unrolled chunk body free of runtime branches, which would cut it into small scheduling regions)
+                const bool stage_here = !C::WS && C::DB && GPC > 2 && !(C::ABL & 2) && g >= G0 && g < G0 + NU;
+                if (stage_here && !kInterleave) write_unit(nxt, g - G0);
+                if (!C::WS && C::DB && GPC > 2 && more && g == G0 + NU && chunk + 2 < p.nchunks && !(C::ABL & 64)) issue_loads(chunk + 2);
+                const int tap = g >> 1, j = g & 1, ky = tap / C::KS, kx = tap % C::KS;
+                int ab = a_base;
+                asm volatile("" : "+v"(ab));                 // no cross-tap CSE of LDS reads (see conv_kernel.h)
+                __builtin_assume((ab & 7) == 0);
+                // operand reads of group gg (same chunk): A fragment of M-tile t, hi plane / lo plane
+                auto rd_a = [&](int gg, int t) __attribute__((always_inline)) {
+                    const int tp = gg >> 1, jj = gg & 1, kyy = tp / C::KS, kxx = tp % C::KS;
+                    a[t] = *reinterpret_cast<const h8*>(&lds[ab + (t * C::RPM * C::STRIDE + kyy) * RSH + kxx * PSH + jj * 16]);
+                };
+                auto rd_al = [&](int gg, int t) __attribute__((always_inline)) {
+                    const int tp = gg >> 1, jj = gg & 1, kyy = tp / C::KS, kxx = tp % C::KS;
+                    al[t] = *reinterpret_cast<const h8*>(&lds[ab + (t * C::RPM * C::STRIDE + kyy) * RSH + kxx * PSH + KC + jj * 16]);
+                };
+                if constexpr (!(C::ABL & 8)) {
+                    if (!kPipe || g == 0) {                  // (kPipe: groups 1.. were read under the previous group's MFMAs)
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) {
+                            rd_a(g, t);
+                            if constexpr (C::SPLIT) rd_al(g, t);
+                        }
+                    }
+                }
+                const h8 bq = ring[g % PF][0];
+                h8 bl;
+                if constexpr (C::SPLIT) bl = ring[g % PF][1];
+                // (kPipe refills each plane of the ring slot right behind the last MFMA that reads it -- below -- so that the old
+                // fragment and its in-flight successor never hold registers at the same time: the pipelined reads need them)
+                if constexpr (!(C::ABL & 4) && !kPipe) {
+#pragma unroll
+                    for (int pl_ = 0; pl_ < C::PLANES; ++pl_)      // wraps into the next chunk / tail pad
+                        ring[g % PF][pl_] = wload(wc + (unsigned)((g + PF) * GH + pl_ * 512));
+                }
+                if constexpr (kPipe) {
+                    // Software-pipelined operand reads (MFMA waves of the wave-specialised tile): the NEXT group's A fragments are
+                    // read under THIS group's MFMAs, into the registers the group has just finished with -- no extra registers.
+                    // SPLIT order hi*hi, hi*lo, lo*hi: after the 8 MFMAs that use the hi fragments a[0..3] are dead and the next
+                    // group's hi reads fly under the four lo*hi MFMAs (128 matrix-pipe cycles ~ the LDS latency); each lo fragment
+                    // is re-read right behind its own lo*hi MFMA and is not needed for 8 MFMAs.  Without this every group began with
+                    // 8 ds_read_b128 and an lgkmcnt wait in front of its first MFMA, covered only by the SIMD's other MFMA wave
+                    // (tools/ws_stamps.py: a wave keeps the pipe ~58 % busy alone).  sched_barriers pin the order: hipcc sinks the
+                    // reads back in front of their own MFMAs otherwise (round 3's persistent kernel: 0.76 -> 0.70 ms).
+                    const bool nxt_in_chunk = g + 1 < GPC;
+                    if constexpr (C::SPLIT) {
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) acc[t] = mfma_32x32x16(a[t], bq, acc[t]);
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) acc[t] = mfma_32x32x16(a[t], bl, acc[t]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (!(C::ABL & 4)) ring[g % PF][1] = wload(wc + (unsigned)((g + PF) * GH + 512));      // (lo plane: dead now)
+                        if constexpr (!(C::ABL & 8)) {
+                            if (nxt_in_chunk) {
+#pragma unroll
+                                for (int t = 0; t < MT; ++t) rd_a(g + 1, t);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) {
+                            acc[t] = mfma_32x32x16(al[t], bq, acc[t]);
+                            if constexpr (!(C::ABL & 8)) {
+                                if (nxt_in_chunk) rd_al(g + 1, t);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (!(C::ABL & 4)) ring[g % PF][0] = wload(wc + (unsigned)((g + PF) * GH));
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) {
+                            acc[t] = mfma_32x32x16(a[t], bq, acc[t]);
+                            if constexpr (!(C::ABL & 8)) {
+                                if (nxt_in_chunk) rd_a(g + 1, t);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (!(C::ABL & 4)) ring[g % PF][0] = wload(wc + (unsigned)((g + PF) * GH));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    continue;
+                }
+                // MFMA m of the group: term m / MT (hi*hi, lo*hi, hi*lo; lo*lo <= 2^-22 of the product is dropped), tile m % MT
+                auto mfma_at = [&](int m) {
+                    const int t = m % MT, term = m / MT;
+                    acc[t] = mfma_32x32x16(term == 1 ? al[t] : a[t], term == 2 ? bl : bq, acc[t]);
+                };
+                if (kInterleave && stage_here) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                        for (int m = k * NM / 4; m < (k + 1) * NM / 4; ++m) mfma_at(m);      // (NM = 6: quarters of 1, 2, 1, 2)
+                        if ((k & 1) == 0 && k / 2 < EPU / 2) unit_pair(g - G0, k / 2);      // pairs ride on quarters 0 and 2
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    unit_store(nxt, g - G0);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) mfma_at(m);
+                }
+            }
+        }
+        timed_barrier();
+        if (chunk < 8) stamp(3 + chunk);
+        if constexpr (!C::DB) {      // single image: every wave is done reading it; write the next chunk in place
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < NPASS; ++i) write_pass(nxt, i);
+                if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ----
+    if (!nvalid) return;
     if constexpr (C::ABL & 1) {
         float keep = 0.f;
 #pragma unroll
@@ -713,7 +828,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             if (!nok) am = 0.f;
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) am = fmaxf(am, __shfl_xor(am, off));
-            if (lane == 0) amax_publish(p.amax_out, b, (tile_id * 4 + wv) * 5 + by, am);
+            if (lane == 0) amax_publish(p.amax_out, b, (bx0 * 4 + wv) * 5 + by, am);
         }
         return;
     }
@@ -890,185 +1005,6 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
             }
         }
     }
-    };
-    h8 a[MT], al[MT];
-    // ---- the workgroup's tiles, one after the other (4-wave kernels: one) ----
-    for (int qi = 0; qi < nseq; ++qi) {
-    if (qi > 0) {
-        if constexpr (C::WS) set_geo(T0 + qi); else set_tile(T0 + qi);
-    }
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    if constexpr (kAccInit) {
-        if (!asc.late) add_terms(std::true_type{}, 1.f, asc.inv);
-    }
-#pragma unroll
-    for (int j = 0; j < PF; ++j)
-#pragma unroll
-        for (int pl_ = 0; pl_ < C::PLANES; ++pl_) ring[j][pl_] = wload(j * GH + pl_ * 512);
-    if (qi == 0) {
-        if constexpr (!C::WS) {
-            issue_loads(0);
-            stamp(1);
-#pragma unroll
-            for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
-            if (p.nchunks > 1 && !(C::ABL & 2)) issue_loads(1);
-        }
-        __syncthreads();
-        stamp(2);
-        if constexpr (C::ABL & 8) {                 // ablation: operands read once
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                a[t] = *reinterpret_cast<const h8*>(&lds_all[a_base + t * C::RPM * C::STRIDE * RSH]);
-                al[t] = *reinterpret_cast<const h8*>(&lds_all[a_base + t * C::RPM * C::STRIDE * RSH + 16]);
-            }
-        }
-    }
-    const int kbase = qi * p.nchunks;              // image parity runs over the workgroup's flat chunk sequence (producer loop)
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        const H* lds = lds_all + (C::DB ? ((kbase + chunk) & 1) * C::LDS_HALVES : 0);
-        H* nxt = lds_all + (C::DB ? ((kbase + chunk + 1) & 1) * C::LDS_HALVES : 0);
-        const bool more = chunk + 1 < p.nchunks && !(C::ABL & 2);
-        if (!C::WS && C::DB && (!nvalid || GPC <= 2)) {
-            // a wave without output channels (or a 1x1 layer: two groups per chunk) stages in one go
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < NPASS; ++i) write_pass(nxt, i);
-                if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
-            }
-        }
-        if (nvalid) {
-            const unsigned wc = (unsigned)chunk * (unsigned)(TAPS * 2 * GH);      // halves, scalar
-#pragma unroll
-            for (int g = 0; g < GPC; ++g) {
-                // Staging groups (g in [G0, G0 + NU), next chunk exists): the unit's four channel computations are placed
-                // BETWEEN quarters of the group's MFMAs, fenced by sched_barriers -- left alone the scheduler emits the unit's
-                // ~60 VALU instructions as one clump in front of the group's first MFMA (and sched_group_barrier pipelines
-                // did not move them).  A quarter = 3 MFMAs (96 matrix-pipe cycles) + ~14 VALU instructions.
-                constexpr int NM = MT * (C::SPLIT ? 3 : 1);                  // MFMAs per group
-                constexpr bool kInterleave = C::DB && GPC > 2 && NM >= 4 && !(C::ABL & 128);
-                // (compile-time: in the LAST chunk the unit restages stale registers into the idle image -- harmless, and it
-                // keeps the unrolled chunk body free of runtime branches, which would cut it into small scheduling regions)
-                const bool stage_here = !C::WS && C::DB && GPC > 2 && !(C::ABL & 2) && g >= G0 && g < G0 + NU;
-                if (stage_here && !kInterleave) write_unit(nxt, g - G0);
-                if (!C::WS && C::DB && GPC > 2 && more && g == G0 + NU && chunk + 2 < p.nchunks && !(C::ABL & 64)) issue_loads(chunk + 2);
-                const int tap = g >> 1, j = g & 1, ky = tap / C::KS, kx = tap % C::KS;
-                int ab = a_base;
-                asm volatile("" : "+v"(ab));                 // no cross-tap CSE of LDS reads (see conv_kernel.h)
-                __builtin_assume((ab & 7) == 0);
-                // operand reads of group gg (same chunk): A fragment of M-tile t, hi plane / lo plane
-                auto rd_a = [&](int gg, int t) __attribute__((always_inline)) {
-                    const int tp = gg >> 1, jj = gg & 1, kyy = tp / C::KS, kxx = tp % C::KS;
-                    a[t] = *reinterpret_cast<const h8*>(&lds[ab + (t * C::RPM * C::STRIDE + kyy) * RSH + kxx * PSH + jj * 16]);
-                };
-                auto rd_al = [&](int gg, int t) __attribute__((always_inline)) {
-                    const int tp = gg >> 1, jj = gg & 1, kyy = tp / C::KS, kxx = tp % C::KS;
-                    al[t] = *reinterpret_cast<const h8*>(&lds[ab + (t * C::RPM * C::STRIDE + kyy) * RSH + kxx * PSH + KC + jj * 16]);
-                };
-                if constexpr (!(C::ABL & 8)) {
-                    if (!kPipe || g == 0) {                  // (kPipe: groups 1.. were read under the previous group's MFMAs)
-#pragma unroll
-                        for (int t = 0; t < MT; ++t) {
-                            rd_a(g, t);
-                            if constexpr (C::SPLIT) rd_al(g, t);
-                        }
-                    }
-                }
-                const h8 bq = ring[g % PF][0];
-                h8 bl;
-                if constexpr (C::SPLIT) bl = ring[g % PF][1];
-                // (kPipe refills each plane of the ring slot right behind the last MFMA that reads it -- below -- so that the old
-                // fragment and its in-flight successor never hold registers at the same time: the pipelined reads need them)
-                if constexpr (!(C::ABL & 4) && !kPipe) {
-#pragma unroll
-                    for (int pl_ = 0; pl_ < C::PLANES; ++pl_)      // wraps into the next chunk / tail pad
-                        ring[g % PF][pl_] = wload(wc + (unsigned)((g + PF) * GH + pl_ * 512));
-                }
-                if constexpr (kPipe) {
-                    // Software-pipelined operand reads (MFMA waves of the wave-specialised tile): the NEXT group's A fragments are
-                    // read under THIS group's MFMAs, into the registers the group has just finished with -- no extra registers.
-                    // SPLIT order hi*hi, hi*lo, lo*hi: after the 8 MFMAs that use the hi fragments a[0..3] are dead and the next
-                    // group's hi reads fly under the four lo*hi MFMAs (128 matrix-pipe cycles ~ the LDS latency); each lo fragment
-                    // is re-read right behind its own lo*hi MFMA and is not needed for 8 MFMAs.  Without this every group began with
-                    // 8 ds_read_b128 and an lgkmcnt wait in front of its first MFMA, covered only by the SIMD's other MFMA wave
-                    // (tools/ws_stamps.py: a wave keeps the pipe ~58 % busy alone).  sched_barriers pin the order: hipcc sinks the
-                    // reads back in front of their own MFMAs otherwise (round 3's persistent kernel: 0.76 -> 0.70 ms).
-                    const bool nxt_in_chunk = g + 1 < GPC;
-                    if constexpr (C::SPLIT) {
-#pragma unroll
-                        for (int t = 0; t < MT; ++t) acc[t] = mfma_32x32x16(a[t], bq, acc[t]);
-#pragma unroll
-                        for (int t = 0; t < MT; ++t) acc[t] = mfma_32x32x16(a[t], bl, acc[t]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (!(C::ABL & 4)) ring[g % PF][1] = wload(wc + (unsigned)((g + PF) * GH + 512));      // (lo plane: dead now)
-                        if constexpr (!(C::ABL & 8)) {
-                            if (nxt_in_chunk) {
-#pragma unroll
-                                for (int t = 0; t < MT; ++t) rd_a(g + 1, t);
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int t = 0; t < MT; ++t) {
-                            acc[t] = mfma_32x32x16(al[t], bq, acc[t]);
-                            if constexpr (!(C::ABL & 8)) {
-                                if (nxt_in_chunk) rd_al(g + 1, t);
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (!(C::ABL & 4)) ring[g % PF][0] = wload(wc + (unsigned)((g + PF) * GH));
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < MT; ++t) {
-                            acc[t] = mfma_32x32x16(a[t], bq, acc[t]);
-                            if constexpr (!(C::ABL & 8)) {
-                                if (nxt_in_chunk) rd_a(g + 1, t);
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (!(C::ABL & 4)) ring[g % PF][0] = wload(wc + (unsigned)((g + PF) * GH));
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    continue;
-                }
-                // MFMA m of the group: term m / MT (hi*hi, lo*hi, hi*lo; lo*lo <= 2^-22 of the product is dropped), tile m % MT
-                auto mfma_at = [&](int m) {
-                    const int t = m % MT, term = m / MT;
-                    acc[t] = mfma_32x32x16(term == 1 ? al[t] : a[t], term == 2 ? bl : bq, acc[t]);
-                };
-                if (kInterleave && stage_here) {
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                        for (int m = k * NM / 4; m < (k + 1) * NM / 4; ++m) mfma_at(m);      // (NM = 6: quarters of 1, 2, 1, 2)
-                        if ((k & 1) == 0 && k / 2 < EPU / 2) unit_pair(g - G0, k / 2);      // pairs ride on quarters 0 and 2
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    unit_store(nxt, g - G0);
-                } else {
-#pragma unroll
-                    for (int m = 0; m < NM; ++m) mfma_at(m);
-                }
-            }
-        }
-        timed_barrier();
-        if (chunk < 8) stamp(3 + chunk);
-        if constexpr (!C::DB) {      // single image: every wave is done reading it; write the next chunk in place
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < NPASS; ++i) write_pass(nxt, i);
-                if (chunk + 2 < p.nchunks) issue_loads(chunk + 2);
-            }
-            __syncthreads();
-        }
-    }
-
-    if (nvalid) run_epilogue(qi);
-    }      // tiles of the sequence
 }
 
 template <class C, int STG>
@@ -1104,8 +1040,8 @@ __global__ __launch_bounds__(512, 4) void conv16_ws_kernel(const Conv16Params p)
     conv16_body<C, STG, 1>(p, lds_all, bx, by);
 }
 
-#include <stdlib.h>
 #ifdef CDX_TUNING
+#include <stdlib.h>
 // tuning build only: CDX_NO_WS=1 routes the wave-specialised launches to the 4-wave kernel of the same configuration (same-box
 // A/B of whole bench runs: tools/session/gpu_r3h.sh)
 inline bool ws_disabled() {
@@ -1117,26 +1053,12 @@ inline bool ws_disabled() {
 template <class C>
 inline int conv16_launch(const Conv16Params& p, hipStream_t stream);
 
-// Tiles per workgroup sequence of a wave-specialised launch (Conv16Params::seq): as long as the launch still has several
-// workgroups per resident slot (2 per CU x 256 CUs) to even out the tail, up to 4 tiles share one prologue.
-inline int conv16_ws_seq(int ntiles, int nblocks_y) {
-#ifdef CDX_TUNING
-    static const int forced = [] { const char* e = getenv("CDX_SEQ"); return e ? atoi(e) : 0; }();
-    if (forced > 0) return forced;
-#endif
-    const long wgs = (long)ntiles * nblocks_y;
-    return wgs >= 4 * 2048 ? 4 : wgs >= 2 * 2048 ? 2 : 1;
-}
-
 template <class C>
-inline int conv16_ws_launch(const Conv16Params& p0, hipStream_t stream) {
+inline int conv16_ws_launch(const Conv16Params& p, hipStream_t stream) {
 #ifdef CDX_TUNING
-    if (ws_disabled()) return conv16_launch<Conv16Cfg<C::KS, C::STRIDE, C::LOGTW, C::MT, C::PF, C::ABL, C::SPLIT, C::DB, C::BF, 0>>(p0, stream);
+    if (ws_disabled()) return conv16_launch<Conv16Cfg<C::KS, C::STRIDE, C::LOGTW, C::MT, C::PF, C::ABL, C::SPLIT, C::DB, C::BF, 0>>(p, stream);
 #endif
-    Conv16Params p = p0;
-    const int ntiles = p.tiles_x * p.tiles_y * p.B;
-    if (p.seq <= 0) p.seq = conv16_ws_seq(ntiles, ceil_div(p.Cout, C::BN));
-    dim3 grid(ceil_div(ntiles, p.seq), ceil_div(p.Cout, C::BN));
+    dim3 grid(p.tiles_x * p.tiles_y * p.B, ceil_div(p.Cout, C::BN));
     switch (p.gn ? (p.silu ? 2 : 1) : (p.silu ? 3 : 0)) {
         case 0: hipLaunchKernelGGL((conv16_ws_kernel<C, 0>), grid, dim3(512), 0, stream, p); break;
         case 1: hipLaunchKernelGGL((conv16_ws_kernel<C, 1>), grid, dim3(512), 0, stream, p); break;

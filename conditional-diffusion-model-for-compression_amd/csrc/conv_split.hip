@@ -199,7 +199,6 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     p.out = a->out; p.out_f32 = 1; p.out_ld = a->out_ld; p.stats = a->stats_out;
     p.stats_wm = conv_split_slots_per_tile(a);
     p.ostep = 1; p.ody = p.odx = 0; p.pady = p.padx = a->ksize / 2; p.slot_base = 0; p.nslots_total = 0;
-    p.seq = 0;            // wave-specialised launches: tiles per workgroup chosen by conv16_ws_launch
     p.act_exp = (a->flags & CDX_CONV_GN_EXP) ? a->gn_exp : 0;
     p.amax[0] = (a->flags & CDX_CONV_GN) ? nullptr : a->src_amax0;
     p.amax[1] = (a->flags & CDX_CONV_GN) || a->c1 == 0 ? nullptr : a->src_amax1;
@@ -250,16 +249,10 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
         return conv_kpar_launch<KparCfg<1, 3>>(p, stream);
     }
 #ifdef CDX_TUNING
-    if (a->ksize == 3 && variant == 50) { p.seq = 1; return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 4096, 1, 1, 0, 1>>(p, stream); }      // the shipped tile WITHOUT pipelined operand reads
-    if (a->ksize == 3 && variant >= 53 && variant <= 56) {      // the shipped tile with 1 / 2 / 4 / 8 tiles per workgroup sequence
-        p.seq = 1 << (variant - 53);
-        return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 2, 0, 1, 1, 0, 1>>(p, stream);
-    }
-    if (a->ksize == 3 && variant == 57) { p.seq = 1; return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 0, 1, 1, 0, 1>>(p, stream); }      // ring depth 3, one tile per workgroup (round 4, call b)
+    if (a->ksize == 3 && variant == 50) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 4096, 1, 1, 0, 1>>(p, stream);      // the shipped tile WITHOUT pipelined operand reads
     if (a->ksize == 3 && variant == 52) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 8192, 1, 1, 0, 1>>(p, stream);      // the shipped tile in the XCD-contiguous workgroup order (measured, not shipped: conv16_kernel.h)
-    if (a->ksize == 3 && variant == 51) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 2, 0, 1, 1, 0, 1>>(p, stream);         // the shipped tile (same code path as tile 11)
+    if (a->ksize == 3 && variant == 51) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 0, 1, 1, 0, 1>>(p, stream);         // the shipped tile (same code path as tile 11)
     if (a->ksize == 3 && (variant == 48 || variant == 49)) {      // the SHIPPED 8 x 16 tile with per-wave stamps / barrier accounting (tools/ws_stamps.py)
-        p.seq = 1;        // (the stamp digest reads one row per tile)
         if (variant == 48) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 544, 1, 1, 0, 1>>(p, stream);
         return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 546, 1, 1, 0, 1>>(p, stream);       // ... producers stage only the first chunk
     }
@@ -308,7 +301,7 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     // 3x3 at >= 32 pixels wide (79 % of the cfg2 step): the WAVE-SPECIALISED workgroup -- 4 MFMA waves + 4 producer waves
     // (conv16_kernel.h WS): bit-identical to the 4-wave tile, +3...5 % (in-process A/B, profiles/r03_*); the HBM-bound 1x1
     // layers gain nothing from it and keep the 4-wave form
-    if (a->ksize == 3) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 2, 0, 1, 1, 0, 1>>(p, stream);      // 8 x 16-pixel tile (conv_split_tile_shape)
+    if (a->ksize == 3) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 0, 1, 1, 0, 1>>(p, stream);      // 8 x 16-pixel tile (conv_split_tile_shape)
     return conv16_launch<Conv16Cfg<1, 1, 5, 4, 3, 0, 1>>(p, stream);
 }
 }  // namespace cdx
