@@ -18,6 +18,7 @@ from cdx import ops, _abi
 ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="16,256,256,128,0,128")
 ap.add_argument("--tile", type=int, default=108)
+ap.add_argument("--nores", action="store_true", help="no residual (a ResBlock's conv1: GroupNorm + SiLU + temb only)")
 ap.add_argument("--fp16", action="store_true", help="the 16-bit storage tile (cdx_conv_f16, tuning flag bits 8..11 = 10) instead of the float32 split tile")
 a = ap.parse_args()
 B, H, W, c0, c1, co = map(int, a.shape.split(","))
@@ -35,7 +36,7 @@ if a.fp16:
     out = torch.empty(B, H, W, co, device="cuda", dtype=torch.float16)
     sc, sh = torch.ones(B, c0, device="cuda"), torch.zeros(B, c0, device="cuda")
     args = ops.conv16_args(pc, x0, None, out, gn=(sc, sh), silu=True, temb=torch.randn(B, co, device="cuda"),
-                           residual=torch.randn(B, H, W, co, device="cuda").half())
+                           residual=None if a.nores else torch.randn(B, H, W, co, device="cuda").half())
     args.flags |= 10 << 8                            # tuning flag bits 8..11: the stamping variant of the 16-bit tile
     _keep = ops.conv16_stats_buffer(args, "cuda")
     args.stats_out = big.data_ptr()
@@ -47,7 +48,7 @@ else:
     out = torch.empty(B, H, W, co, device="cuda")
     gamma, beta = torch.ones(c0 + c1, device="cuda"), torch.zeros(c0 + c1, device="cuda")
     kw = dict(gn=ops.gn_stats(x0, x1, gamma, beta, 32, act_exp="auto"), silu=True, temb=torch.randn(B, co, device="cuda"),
-              residual=torch.randn(B, H, W, co, device="cuda"))
+              residual=None if a.nores else torch.randn(B, H, W, co, device="cuda"))
     args = ops.conv_args(pc, x0, x1, out, **kw)
     _keep = ops.conv_stats_buffer(args, "cuda")      # sets stats_slots
     args.stats_out = big.data_ptr()
