@@ -563,58 +563,8 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                 for (int r = 0; r < 16; ++r) acc[t][r] = FIRST ? add : fmaf(acc[t][r], macc, add);
         }
     };
-    // Wave-specialised tiles fetch the residual in TWO PHASES: the loads are issued here, straight into the accumulator registers
-    // (raw bits), and the scaling FMAs that consume them run BEHIND the first barrier.  With the FMAs (and their vmcnt waits) in
-    // front of the barrier the MFMA waves reached it only when their own 64 dword loads per lane were back -- tools/ws_stamps.py:
-    // entry -> first chunk staged 9.7 us with a residual against 6.3 us without (16-bit: 5.9 / 4.7), i.e. the wave that has nothing
-    // else to do waited longer for ITS fetch than the producers needed to load and stage the whole first chunk.
-    float init_add = 0.f;
-    bool init_pending = false;                               // wave-uniform
-    auto init_fetch = [&]() __attribute__((always_inline)) {
-        init_pending = true;
-        const int n = ntile * 32 + li;
-        if (!(nvalid && n < p.Cout)) return;
-        if (!bias_late) {
-            init_add = p.bias ? p.bias[n] : 0.f;
-            if (p.temb) init_add += p.temb[(size_t)b * p.temb_ld + n];
-            init_add *= asc.inv;
-        }
-        constexpr unsigned es = C::SPLIT ? 4u : 2u;
-        const size_t first = (((size_t)b * p.Hout + oy0w) * p.Wout + ox0) * p.Cout;      // (bounds: see add_terms)
-        const size_t total = (size_t)p.B * p.Hout * p.Wout * p.Cout;
-        const size_t left = first < total ? (total - first) * es : 1;
-        const __amdgpu_buffer_rsrc_t rr = buf_rsrc(static_cast<const char*>(p.residual) + (first < total ? first : 0) * es,
-                                                   left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)left);
-        const unsigned voff = ((unsigned)(4 * lh) * (unsigned)p.Cout + (unsigned)n) * es;
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int mb = t * 32 + 8 * (r >> 2) + (r & 3);
-                const unsigned pix = (unsigned)(mb >> C::LOGTW) * (unsigned)p.Wout + (unsigned)(mb & (C::TW - 1));
-                if constexpr (C::SPLIT) acc[t][r] = buf_load1(rr, voff, pix * (unsigned)p.Cout * es);
-                else acc[t][r] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_bit_cast(unsigned short, __builtin_amdgcn_raw_buffer_load_b16(rr, voff, pix * (unsigned)p.Cout * es, 0)));
-            }
-    };
-    auto init_apply = [&]() __attribute__((always_inline)) {
-        if (!init_pending) return;
-        const int n = ntile * 32 + li;
-        if (!(nvalid && n < p.Cout)) return;
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float rv;
-                if constexpr (C::SPLIT) rv = acc[t][r];
-                else rv = (float)__builtin_bit_cast(H, (unsigned short)__builtin_bit_cast(unsigned, acc[t][r]));
-                acc[t][r] = fmaf(rv, asc.inv, init_add);
-            }
-    };
     if constexpr (kAccInit) {
-        if (!asc.late) {
-            if (C::WS && p.residual && !(C::ABL & 16) && !(C::ABL & 16384)) init_fetch();      // (ABL 16384, tuning build: round 3's one-phase init)
-            else add_terms(std::true_type{}, 1.f, asc.inv);
-        }
+        if (!asc.late) add_terms(std::true_type{}, 1.f, asc.inv);
     }
 
     h8 ring[PF][C::PLANES];
@@ -640,7 +590,6 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     }
     __syncthreads();
     stamp(2);
-    if constexpr (C::WS && kAccInit) init_apply();
     h8 a[MT], al[MT];
     if constexpr (C::ABL & 8) {                 // ablation: operands read once
 #pragma unroll

@@ -250,7 +250,6 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     }
 #ifdef CDX_TUNING
     if (a->ksize == 3 && variant == 50) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 4096, 1, 1, 0, 1>>(p, stream);      // the shipped tile WITHOUT pipelined operand reads
-    if (a->ksize == 3 && variant == 58) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 16384, 1, 1, 0, 1>>(p, stream);     // the shipped tile with the ONE-phase residual init (FMAs in front of the first barrier)
     if (a->ksize == 3 && variant == 52) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 8192, 1, 1, 0, 1>>(p, stream);      // the shipped tile in the XCD-contiguous workgroup order (measured, not shipped: conv16_kernel.h)
     if (a->ksize == 3 && variant == 51) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 0, 1, 1, 0, 1>>(p, stream);         // the shipped tile (same code path as tile 11)
     if (a->ksize == 3 && (variant == 48 || variant == 49)) {      // the SHIPPED 8 x 16 tile with per-wave stamps / barrier accounting (tools/ws_stamps.py)
