@@ -36,3 +36,22 @@ def test_traffic_digest_selection(tmp_path):
     name, tr, _ = bench.find_traffic_digest("KernelB<", "bbbb", "cfg5", d)
     assert name == "r09_b_traffic_cfg5.json" and tr["config"] == "cfg5"
 
+
+
+def test_parity_object_gates():
+    """bench.parity_object: the gates of SURVEY.md 8d on the driver line -- PSNR(hip, oracle) >= 80 dB always, |PSNR(hip, target) -
+    PSNR(oracle, target)| <= 0.01 dB for a complete decode; a perturbed decode fails, an incomplete one is not judged on the delta."""
+    import torch
+    import bench
+    g = torch.Generator().manual_seed(0)
+    tgt = torch.rand(1, 3, 32, 32, generator=g) * 2 - 1
+    ora = (tgt + 0.3 * torch.randn(1, 3, 32, 32, generator=g)).clamp(-1, 1)
+    ok = bench.parity_object(ora + 1e-5 * torch.randn(1, 3, 32, 32, generator=g), ora, tgt, 100, 100, "test")
+    assert ok["pass"] and ok["complete"] and ok["psnr_hip_vs_oracle_db"] > 100 and ok["psnr_delta_vs_target_db"] < 1e-3
+    assert {"psnr_hip_vs_oracle_db", "psnr_delta_vs_target_db", "max_abs_err", "steps", "image", "gates"} <= set(ok)
+    bad = bench.parity_object(ora + 1e-3 * torch.randn(1, 3, 32, 32, generator=g), ora, tgt, 100, 100, "test")      # ~ 66 dB
+    assert not bad["pass"] and bad["psnr_hip_vs_oracle_db"] < 80
+    drift = bench.parity_object(0.98 * ora, ora, tgt, 100, 100, "test")          # close to the oracle, but not at its distance from the target
+    assert not drift["pass"]
+    part = bench.parity_object(ora + 1e-5 * torch.randn(1, 3, 32, 32, generator=g), ora, tgt, 7, 100, "test")
+    assert part["pass"] and not part["complete"] and part["steps"] == 7
