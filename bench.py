@@ -419,6 +419,10 @@ def main(argv=None, make_sampler=None, dist_backend=None, bind_device=None):
     if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run: a process group for the barrier / max-reduce only
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "gloo" and os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            # single node: gloo's pairwise connections go over loopback (its default picks the interface the HOSTNAME resolves to,
+            # and a container's hostname may not resolve)
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         if backend == "nccl" and not injected:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
