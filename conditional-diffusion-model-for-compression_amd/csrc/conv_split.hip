@@ -252,6 +252,12 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     if (a->ksize == 3 && variant == 50) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 4096, 1, 1, 0, 1>>(p, stream);      // the shipped tile WITHOUT pipelined operand reads
     if (a->ksize == 3 && variant == 52) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 8192, 1, 1, 0, 1>>(p, stream);      // the shipped tile in the XCD-contiguous workgroup order (measured, not shipped: conv16_kernel.h)
     if (a->ksize == 3 && variant == 51) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 0, 1, 1, 0, 1>>(p, stream);         // the shipped tile (same code path as tile 11)
+    if (a->ksize == 3 && variant >= 59 && variant <= 62) {      // stamped timing ablations of the shipped tile: what does the CLOCK do without ... (tools/ws_stamps.py --tile 119 .. 122)
+        if (variant == 59) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 552, 1, 1, 0, 1>>(p, stream);       // ... the LDS operand reads
+        if (variant == 60) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 548, 1, 1, 0, 1>>(p, stream);       // ... the weight refills
+        if (variant == 61) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 558, 1, 1, 0, 1>>(p, stream);       // ... all three (MFMAs + barriers + epilogue only)
+        return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 545, 1, 1, 0, 1>>(p, stream);                           // ... the epilogue
+    }
     if (a->ksize == 3 && (variant == 48 || variant == 49)) {      // the SHIPPED 8 x 16 tile with per-wave stamps / barrier accounting (tools/ws_stamps.py)
         if (variant == 48) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 544, 1, 1, 0, 1>>(p, stream);
         return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 546, 1, 1, 0, 1>>(p, stream);       // ... producers stage only the first chunk
