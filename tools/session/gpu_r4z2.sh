@@ -6,6 +6,13 @@ R=$PWD
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$R}
 step r4z_bench_cfg2 600 python bench.py --details
 grep "^{" gpurun_out/r4z_bench_cfg2.log | head -1 > gpurun_out/r4z_bench_cfg2.json
+python - <<'PY'
+t = open("gpurun_out/r4z_bench_cfg2.log").read()
+i = t.find('{\n "conv_variants"')
+if i >= 0:
+    j = t.find("\n{\"metric\"", i)
+    open("gpurun_out/r4z_conv_shapes.json", "w").write(t[i:j if j > 0 else None])
+PY
 step r4z_bench_cfg4 500 python bench.py --config cfg4 --steps 10 --warmup 2 --cpu-budget 30
 step r4z_bench_cfg5 400 python bench.py --config cfg5 --steps 20 --warmup 2
 step r4z_bench_cfg5_bf16 300 python bench.py --config cfg5 --dtype bf16 --steps 20 --warmup 2 --no-cpu-baseline --no-sample-call
@@ -37,5 +44,7 @@ prof r4z5_write "WRITE_SIZE" --config cfg5 --steps 2 --warmup 1 $Q
 prof r4z5_mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" --config cfg5 --steps 2 --warmup 1 $Q
 cd $R
 # keep the merge small: counter / stats csv only
-find gpurun_out/r4z*_* -type f ! -name "*counter_collection.csv" ! -name "*kernel_stats.csv" -delete 2>/dev/null
+for d in gpurun_out/r4z_stats gpurun_out/r4z_fetch gpurun_out/r4z_write gpurun_out/r4z_mfma gpurun_out/r4z4_* gpurun_out/r4z5_*; do
+    [ -d "$d" ] && find "$d" -type f ! -name "*counter_collection.csv" ! -name "*kernel_stats.csv" -delete 2>/dev/null
+done
 ls gpurun_out | grep r4z | head -40
