@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../.." && . tools/session/r4lib.sh
 R=$PWD
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$R}
 step r4z_bench_cfg2 600 python bench.py --details
-grep "^{" gpurun_out/r4z_bench_cfg2.log | head -1 > gpurun_out/r4z_bench_cfg2.json
+grep '^{"metric"' gpurun_out/r4z_bench_cfg2.log | head -1 > gpurun_out/r4z_bench_cfg2.json
 python - <<'PY'
 t = open("gpurun_out/r4z_bench_cfg2.log").read()
 i = t.find('{\n "conv_variants"')
