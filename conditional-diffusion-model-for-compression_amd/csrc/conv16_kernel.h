@@ -454,14 +454,6 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         for (int h = 0; h < UPP; ++h) write_unit(lds, UPP * i + h);
     };
 
-    // WIDE EPILOGUE (float32 wave-specialised 8 x 16 tile, full 128-channel blocks): the MFMA waves put the finished tile through LDS (two
-    // halves of 64 pixels x 128 channels x 4 B = 32 KiB in the halo images, free after the last chunk) and store it as 16-byte
-    // rows -- 16 store instructions per lane instead of 64 single dwords, full 512-byte pixel rows instead of 128-byte quarters.
-    // Three workgroup barriers; the producer waves stay for them (a barrier some waves never reach must not be relied on).
-    // Workgroup-uniform by construction (launch parameters and the channel-block index only).  ABL 32768 (tuning build): off.
-    constexpr bool kWideCfg = C::WS && C::SPLIT && WM == 1 && MT == 4 && C::LOGTW == 4 && C::DB && !(C::ABL & (1 | 32768));
-    static_assert(!kWideCfg || 2 * C::LDS_HALVES * 2 >= 64 * 128 * 4, "the half tile must fit the halo images");
-    const bool wide = kWideCfg && p.ostep == 1 && (by + 1) * C::BN <= p.Cout && (p.out_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15u) == 0;
     if constexpr (C::WS) {
         if (producer) {      // ---- producer waves: stage every chunk, one barrier per chunk in step with the MFMA waves ----
             issue_loads(0);
@@ -484,11 +476,6 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
                 unsigned long long* row = reinterpret_cast<unsigned long long*>(p.stats) + ((size_t)(gridDim.y * gridDim.x + blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 16;
                 const unsigned long long te = memtime();
                 if (lane == 0) { row[1] = bar_ticks; row[2] = stage_ticks; row[3] = te; }
-            }
-            if (wide) {      // the three barriers of the MFMA waves' wide epilogue
-                __syncthreads();
-                __syncthreads();
-                __syncthreads();
             }
             return;
         }
@@ -820,51 +807,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
         };
         using T_ = std::true_type;
         using F_ = std::false_type;
-        // wide form: the same values (and the same sums, in the same order) go to LDS in the accumulator layout and leave it as rows
-        auto wide_store = [&](auto has_stats) __attribute__((always_inline)) {
-            if constexpr (kWideCfg) {
-                float* T = reinterpret_cast<float*>(lds_all);                     // [64 pixels][128 channels]
-                const size_t tfirst = (((size_t)b * p.Hout + oy0) * p.Wout + ox0) * p.out_ld;      // the tile's origin: always inside the image
-                const size_t tleft = ((size_t)p.B * p.Hout * p.Wout * p.out_ld - tfirst) * 4;
-                const __amdgpu_buffer_rsrc_t trs = buf_rsrc(static_cast<float*>(p.out) + tfirst, tleft > 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)tleft);
-                const int c4 = 4 * (lane & 31);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int t = 2 * h + tt;
-                            const int mb = t * 32 + 8 * (r >> 2) + (r & 3);
-                            const int row = mb >> C::LOGTW, col = mb & (C::TW - 1);
-                            const float x = fmaf(acc[t][r], un, addv);
-                            if constexpr (decltype(has_stats)::value) {
-                                const bool ok = oy0 + row < p.Hout && ox0 + col + 4 * lh < p.Wout;
-                                const float xs = ok ? x : 0.f;
-                                const double d = (double)xs;
-                                s1 += d;
-                                s2 = fma(d, d, s2);
-                                am = fmaxf(am, fabsf(xs));
-                            }
-                            T[(mb - 64 * h + 4 * lh) * 128 + 32 * wn + li] = x;
-                        }
-                    __syncthreads();
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int pl_ = 16 * wn + 2 * i + (lane >> 5);           // pixel of this half the lane stores 16 bytes of
-                        const int px = 64 * h + pl_;
-                        const int row = px >> C::LOGTW, col = px & (C::TW - 1);
-                        const bool ok = oy0 + row < p.Hout && ox0 + col < p.Wout;
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(&T[pl_ * 128 + c4]);
-                        const unsigned off = (((unsigned)row * (unsigned)p.Wout + (unsigned)col) * (unsigned)p.out_ld + (unsigned)(by * C::BN + c4)) * 4u;
-                        buf_store4(trs, ok ? off : kDrop, 0u, v);
-                    }
-                    if (h == 0) __syncthreads();      // (every lane's rows of half 0 are in registers: the stores above needed them)
-                }
-            }
-        };
-        if (wide) { if (want_stats) wide_store(T_{}); else wide_store(F_{}); }
-        else if (full) { if (want_stats) direct(T_{}, T_{}); else direct(T_{}, F_{}); }
+        if (full) { if (want_stats) direct(T_{}, T_{}); else direct(T_{}, F_{}); }
         else      { if (want_stats) direct(F_{}, T_{}); else direct(F_{}, F_{}); }
         stamp(12);
         if constexpr (C::WS && (C::ABL & 512) != 0) {
