@@ -22,7 +22,9 @@ complete Sampler.sample() of this rank's shard (x_T draw, all steps, export) aft
 process, before anything touches the GPU), forwards rank 0's JSON line and exits with the child's status.
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel symbol (the conv instantiation carrying most FLOPs): `achieved` = ALGORITHMIC FLOPs of
+  roofline     -- (`traffic`: HBM bytes per launch of that kernel measured in THIS run by two short rocprofv3 --pmc child runs; the
+                  committed digest under profiles/ is the fallback and is kept beside it as `traffic_digest`)
+                  the dominant kernel symbol (the conv instantiation carrying most FLOPs): `achieved` = ALGORITHMIC FLOPs of
                   its launches in one forward / their summed durations (HIP events on the launch stream); `frac` (=
                   `frac_algorithmic`) = achieved / dense peak of the MFMA instruction it issues.  The float32 path issues 3
                   fp16 MFMAs per product (`emulation_factor` 3: frac <= 1/3); `mfma_pipe_utilisation` = the MFMA FLOPs it
@@ -164,6 +166,55 @@ def find_traffic_digest(pattern, sha, workload, directory=None):
         if stale is None:
             stale = {"file": f"profiles/{name}", "csrc_sha16": tr.get("csrc_sha16"), "hbm_bytes_per_launch": round(tr["hbm_bytes_per_launch"])}
     return None, None, stale
+
+
+def live_traffic(pattern: str, workload: str, extra_args=(), timeout_s: float = 150.0):
+    """HBM bytes per launch of the kernel `pattern`, MEASURED IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate
+    runs, as MI355X_MICROARCH.md's HBM section prescribes) over a short child run of this same bench.py (2 steps of the same workload,
+    nothing else), started as ordinary child processes of this one (no exec), each in its own process group with a hard time limit.
+    bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies a 128-byte read request at 64 B; rocprofv3 reports KiB).
+    Returns (bytes per launch | None, description)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    means = {}
+    with tempfile.TemporaryDirectory(dir="/tmp", prefix="cdx_pmc_") as d:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(d, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--config", workload, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-sample-call",
+                   "--no-strict-f32", "--no-live-traffic"] + list(extra_args)
+            try:
+                pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                      start_new_session=True)
+                try:
+                    rc = pr.wait(timeout=timeout_s)
+                except subprocess.TimeoutExpired:
+                    os.killpg(pr.pid, signal.SIGKILL)          # the profiler AND the bench child under it
+                    pr.wait()
+                    return None, f"{ctr} pass exceeded {timeout_s:.0f} s"
+                if rc != 0:
+                    return None, f"{ctr} pass exited with status {rc}"
+            except OSError as e:
+                return None, f"{ctr} pass could not start: {e}"
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for r in csv.DictReader(fh):
+                        if r["Counter_Name"] == ctr and pattern in r["Kernel_Name"]:
+                            vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, f"{ctr} pass: no launch of the kernel in the counter output"
+            means[ctr] = (sum(vals) / len(vals), len(vals))
+    nbytes = 1024.0 * (2.0 * means["FETCH_SIZE"][0] + means["WRITE_SIZE"][0])
+    return nbytes, (f"live: two rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE) over `bench.py --config {workload} --steps 2 --warmup 1` as "
+                    f"child processes of this run; mean over {means['FETCH_SIZE'][1]} launches; 2 x FETCH + WRITE")
 
 
 def measure_dominant_kernel(plan, torch, reps=3, workload="cfg2"):
@@ -394,6 +445,8 @@ def main(argv=None, make_sampler=None, dist_backend=None, bind_device=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sample-call", action="store_true", help="skip the extra timing of one complete Sampler.sample()")
     ap.add_argument("--no-strict-f32", action="store_true", help="skip the extra step loop on the f32-input MFMA kernels (strict_f32)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC digest only (default: measured in this run by two "
+                                                                   "short rocprofv3 --pmc child runs, ~1 min; the digest is the fallback)")
     ap.add_argument("--dtype", default=None, choices=["fp32", "fp16", "bf16"], help="override the config's storage dtype (e.g. cfg2 in fp16 / bf16)")
     ap.add_argument("--no-split", action="store_true", help="A/B: float32 layers on the f32-input MFMA kernels only (no fp16 hi|lo split tile)")
     ap.add_argument("--details", action="store_true", help="print the per-variant conv table to stderr")
@@ -515,6 +568,23 @@ def main(argv=None, make_sampler=None, dist_backend=None, bind_device=None):
             print(json.dumps({"conv_variants": table, "flops": fl}, indent=1), file=sys.stderr)
     if rank == 0 and world == 1 and not injected and not args.no_strict_f32 and not args.no_split and cfg["dtype"] == "fp32":
         line["strict_f32"] = strict_f32_leg(cdx, torch, job, cfg, run, B, tiles_per_image, total_flops, tiled)
+    under_profiler = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)      # (no profiler inside a profiler)
+    if rank == 0 and world == 1 and not injected and "roofline" in line and not args.no_live_traffic and not under_profiler:
+        # HBM traffic of the dominant kernel measured in THIS run (the digest under profiles/ is the builder's number)
+        roof = line["roofline"]
+        try:
+            extra = (["--dtype", args.dtype] if args.dtype else []) + (["--no-split"] if args.no_split else []) + (["--batch", str(args.batch)] if args.batch else [])
+            nbytes, how = live_traffic(roof["pmc_pattern"], args.config, extra)
+        except Exception as e:      # never lose the line to the extra measurement
+            nbytes, how = None, f"failed: {e!r}"
+        if nbytes is not None:
+            if roof.get("traffic") is not None:
+                roof["traffic_digest"] = {"bytes": roof["traffic"], "source": roof.get("traffic_source")}
+            roof["traffic"] = round(nbytes)
+            roof["traffic_over_algorithmic"] = round(nbytes / roof["algorithmic_bytes_per_launch"], 3)
+            roof["traffic_source"] = how
+        else:
+            roof["live_traffic_unavailable"] = how
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not injected:
         c1 = job.cond(0, 1).cpu()
         if tiled:

@@ -24,7 +24,7 @@ def _run(cmd):
 
 @pytest.mark.parametrize("launcher", ["plain", "torchrun", "self_launch"])
 def test_bench_line_contract(lib, launcher):
-    args = ["bench.py", "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-sample-call"]
+    args = ["bench.py", "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-sample-call", "--no-live-traffic"]
     if launcher == "plain":
         cmd = [sys.executable] + args
     elif launcher == "torchrun":
@@ -67,3 +67,16 @@ def test_bench_line_carries_the_parity_object(lib):
     assert par["image"] == 0 and par["of_steps"] == 100 and 2 <= par["steps"] < 100 and par["complete"] is False
     assert par["psnr_hip_vs_oracle_db"] >= 80.0 and par["pass"] is True
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+
+
+def test_bench_measures_the_dominant_kernels_traffic_in_the_run(lib):
+    """roofline.traffic is measured live (two rocprofv3 --pmc child runs of bench.py itself), not only quoted from the committed digest:
+    the figure must lie between the algorithmic bytes and twice them, and be labelled as live."""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not installed")
+    d = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-sample-call", "--no-strict-f32"])
+    roof = d["roofline"]
+    assert "live_traffic_unavailable" not in roof, roof["live_traffic_unavailable"]
+    assert roof["traffic_source"].startswith("live:")
+    assert 1.0 <= roof["traffic"] / roof["algorithmic_bytes_per_launch"] <= 2.0, roof["traffic_over_algorithmic"]

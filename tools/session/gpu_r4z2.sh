@@ -31,14 +31,14 @@ prof() {   # prof <tag> <counters or ""> <bench args...>
     local rc=$?; echo "$tag rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
 }
 Q="--no-cpu-baseline --no-roofline --no-sample-call --no-strict-f32"
-prof r4z_stats "" --steps 10 --warmup 2 --no-cpu-baseline --no-sample-call --no-strict-f32
+prof r4z_stats "" --steps 10 --warmup 2 --no-cpu-baseline --no-sample-call --no-strict-f32 --no-live-traffic
 prof r4z_fetch "FETCH_SIZE" --steps 2 --warmup 1 $Q
 prof r4z_write "WRITE_SIZE" --steps 2 --warmup 1 $Q
 prof r4z_mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" --steps 2 --warmup 1 $Q
-prof r4z4_stats "" --config cfg4 --steps 4 --warmup 1 --no-cpu-baseline --no-sample-call --no-strict-f32
+prof r4z4_stats "" --config cfg4 --steps 4 --warmup 1 --no-cpu-baseline --no-sample-call --no-strict-f32 --no-live-traffic
 prof r4z4_fetch "FETCH_SIZE" --config cfg4 --steps 2 --warmup 1 $Q
 prof r4z4_write "WRITE_SIZE" --config cfg4 --steps 2 --warmup 1 $Q
-prof r4z5_stats "" --config cfg5 --steps 10 --warmup 2 --no-cpu-baseline --no-sample-call
+prof r4z5_stats "" --config cfg5 --steps 10 --warmup 2 --no-cpu-baseline --no-sample-call --no-live-traffic
 prof r4z5_fetch "FETCH_SIZE" --config cfg5 --steps 2 --warmup 1 $Q
 prof r4z5_write "WRITE_SIZE" --config cfg5 --steps 2 --warmup 1 $Q
 prof r4z5_mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" --config cfg5 --steps 2 --warmup 1 $Q
