@@ -80,3 +80,5 @@ def test_bench_measures_the_dominant_kernels_traffic_in_the_run(lib):
     assert "live_traffic_unavailable" not in roof, roof["live_traffic_unavailable"]
     assert roof["traffic_source"].startswith("live:")
     assert 1.0 <= roof["traffic"] / roof["algorithmic_bytes_per_launch"] <= 2.0, roof["traffic_over_algorithmic"]
+    # the matrix-pipe counter of the same runs: unit check against the MFMA count of the launch list, and a busy fraction that makes sense
+    assert 0.97 <= roof["mfma_busy_counter_over_expected"] <= 1.05 and 0.3 <= roof["mfma_busy_frac"] <= 1.0
