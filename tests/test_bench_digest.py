@@ -55,3 +55,45 @@ def test_parity_object_gates():
     assert not drift["pass"]
     part = bench.parity_object(ora + 1e-5 * torch.randn(1, 3, 32, 32, generator=g), ora, tgt, 7, 100, "test")
     assert part["pass"] and not part["complete"] and part["steps"] == 7
+
+
+def _fake_rocprofv3(tmp_path, body):
+    """A stand-in `rocprofv3` on PATH (CPU test of bench.live_traffic's plumbing): parses -d and --pmc like the real tool."""
+    import stat
+    exe = tmp_path / "rocprofv3"
+    exe.write_text("#!/usr/bin/python3\nimport os, sys, time\na = sys.argv[1:]\nd = a[a.index('-d') + 1]\n"
+                   "i = a.index('--pmc') + 1\nctrs = []\nwhile not a[i].startswith('-'):\n    ctrs.append(a[i]); i += 1\n" + body)
+    exe.chmod(exe.stat().st_mode | stat.S_IEXEC)
+    return str(tmp_path)
+
+
+def test_live_traffic_parses_the_counter_passes(tmp_path, monkeypatch):
+    """bench.live_traffic with a stand-in profiler: per-pass means over the launches of the named kernel, 2 x FETCH + WRITE in bytes,
+    the busy fraction against GRBM_GUI_ACTIVE / 8 x 1024 SIMDs; a kernel that never appears, a failing pass and a hanging pass
+    (killed with its whole process group after the time limit) all come back as (None, reason)."""
+    import bench
+    K = "void cdx::conv16_ws_kernel<cdx::Conv16Cfg<3, 1, 4, 4, 3, 0, 1, 1, 0, 1>, 2>(cdx::Conv16Params)"
+    vals = {"FETCH_SIZE": (100.0, 300.0), "WRITE_SIZE": (50.0, 150.0), "SQ_VALU_MFMA_BUSY_CYCLES": (700.0, 700.0), "GRBM_GUI_ACTIVE": (8.0, 8.0)}
+    body = ("vals = %r\nos.makedirs(os.path.join(d, 'runc'), exist_ok=True)\n"
+            "with open(os.path.join(d, 'runc', '1_counter_collection.csv'), 'w') as f:\n"
+            "    f.write('Kernel_Name,Counter_Name,Counter_Value\\n')\n"
+            "    for c in ctrs:\n"
+            "        for v in vals[c]:\n"
+            "            f.write('\"%s\",%%s,%%s\\n' %% (c, v))\n"
+            "        f.write('\"other_kernel\",%%s,12345\\n' %% c)\n") % (vals, K)
+    monkeypatch.setenv("PATH", _fake_rocprofv3(tmp_path, body) + os.pathsep + os.environ["PATH"])
+    res, how = bench.live_traffic("Conv16Cfg<3, 1, 4, 4, 3, 0, 1, 1, 0, 1>", "cfg2")
+    assert res is not None, how
+    nbytes, busy = res
+    assert nbytes == 1024.0 * (2 * 200.0 + 100.0) and how.startswith("live:")
+    assert abs(busy["mfma_busy_frac"] - 700.0 / (8.0 / 8 * 256 * 4)) < 1e-12 and busy["mfma_busy_cycles_per_launch"] == 700.0
+    res, how = bench.live_traffic("no_such_kernel", "cfg2")
+    assert res is None and "no launch of the kernel" in how
+    monkeypatch.setenv("PATH", _fake_rocprofv3(tmp_path, "sys.exit(3)\n") + os.pathsep + os.environ["PATH"])
+    res, how = bench.live_traffic("Conv16Cfg", "cfg2")
+    assert res is None and "status 3" in how
+    monkeypatch.setenv("PATH", _fake_rocprofv3(tmp_path, "time.sleep(60)\n") + os.pathsep + os.environ["PATH"])
+    import time
+    t0 = time.time()
+    res, how = bench.live_traffic("Conv16Cfg", "cfg2", timeout_s=1.0)
+    assert res is None and "exceeded" in how and time.time() - t0 < 20
