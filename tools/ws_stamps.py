@@ -18,6 +18,7 @@ from cdx import ops, _abi
 ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="16,256,256,128,0,128")
 ap.add_argument("--tile", type=int, default=108)
+ap.add_argument("--abl", type=int, default=10, help="--fp16: tuning flag value (10 stamps; 11 .. 15 stamped ablations: no staging / LDS reads / weight refills / epilogue / the first three)")
 ap.add_argument("--nores", action="store_true", help="no residual (a ResBlock's conv1: GroupNorm + SiLU + temb only)")
 ap.add_argument("--fp16", action="store_true", help="the 16-bit storage tile (cdx_conv_f16, tuning flag bits 8..11 = 10) instead of the float32 split tile")
 a = ap.parse_args()
@@ -37,7 +38,7 @@ if a.fp16:
     sc, sh = torch.ones(B, c0, device="cuda"), torch.zeros(B, c0, device="cuda")
     args = ops.conv16_args(pc, x0, None, out, gn=(sc, sh), silu=True, temb=torch.randn(B, co, device="cuda"),
                            residual=None if a.nores else torch.randn(B, H, W, co, device="cuda").half())
-    args.flags |= 10 << 8                            # tuning flag bits 8..11: the stamping variant of the 16-bit tile
+    args.flags |= a.abl << 8                         # tuning flag bits 8..11: the stamping variant of the 16-bit tile (or a stamped ablation)
     _keep = ops.conv16_stats_buffer(args, "cuda")
     args.stats_out = big.data_ptr()
     launch = lambda: L.cdx_conv_f16(ctypes.byref(args), None, 0, st)      # noqa: E731
