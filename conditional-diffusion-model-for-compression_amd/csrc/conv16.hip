@@ -84,6 +84,7 @@ int conv16_dispatch(int ks, int stride, int logtw, int mt, bool bf, const Conv16
             case 3: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 1, 0, 1, 0, 1>>(p, stream);      // ... no epilogue
             case 2: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 3, 0, 1, 0, 1>>(p, stream);      // ... neither
             case 10: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 544, 0, 1, 0, 1>>(p, stream);   // ... per-wave stamps / barrier accounting instead of GroupNorm sums (tools/ws_stamps.py --fp16)
+            case 11: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 65536, 0, 1, 0, 1>>(p, stream);   // ... without the producers' prologue priority
             case 9: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 8192, 0, 1, 0, 1>>(p, stream);   // ... XCD-contiguous workgroup order (measured, not shipped)
             case 8: return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 4096, 0, 1, 0, 1>>(p, stream);   // ... operand reads NOT software-pipelined (round 3's MFMA waves)
             default: return CDX_ENOTSUP;

@@ -243,6 +243,14 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wv % WN, wm = wv / WN;
+    // A new workgroup's producer waves run their ~200-instruction prologue (tile arithmetic, buffer resources) at RAISED priority until the
+    // first halo loads are out: stamped, that prologue took 3.6 us (16-bit tile) / 5.8 us (float32) of the 6 / 10 us the MFMA waves wait for
+    // their first chunk -- its instructions queue behind the resident workgroup's MFMA waves on every SIMD (tools/ws_stamps.py,
+    // profiles/r04_n_*).  ABL 65536 (tuning build): off.
+    constexpr bool kPrio = C::WS && !(C::ABL & 65536);
+    if constexpr (kPrio) {
+        if (producer) __builtin_amdgcn_s_setprio(3);
+    }
 
     const int bx0 = bx;
     const int tx = bx % p.tiles_x;
@@ -457,6 +465,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params& p, typename C::H
     if constexpr (C::WS) {
         if (producer) {      // ---- producer waves: stage every chunk, one barrier per chunk in step with the MFMA waves ----
             issue_loads(0);
+            if constexpr (kPrio) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) write_pass(lds_all, i);
             if (p.nchunks > 1 && !(C::ABL & 2)) issue_loads(1);

@@ -250,6 +250,7 @@ int conv_split_launch(const cdx_conv_args* a, hipStream_t stream, int variant) {
     }
 #ifdef CDX_TUNING
     if (a->ksize == 3 && variant == 50) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 4096, 1, 1, 0, 1>>(p, stream);      // the shipped tile WITHOUT pipelined operand reads
+    if (a->ksize == 3 && variant == 64) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 65536, 1, 1, 0, 1>>(p, stream);     // the shipped tile WITHOUT the producers' prologue priority
     if (a->ksize == 3 && variant == 52) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 8192, 1, 1, 0, 1>>(p, stream);      // the shipped tile in the XCD-contiguous workgroup order (measured, not shipped: conv16_kernel.h)
     if (a->ksize == 3 && variant == 51) return conv16_ws_launch<Conv16Cfg<3, 1, 4, 4, 3, 0, 1, 1, 0, 1>>(p, stream);         // the shipped tile (same code path as tile 11)
     if (a->ksize == 3 && variant >= 59 && variant <= 62) {      // stamped timing ablations of the shipped tile: what does the CLOCK do without ... (tools/ws_stamps.py --tile 119 .. 122)

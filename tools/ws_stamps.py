@@ -87,4 +87,8 @@ for k, v in seg.items():
     print(f"  {k:46s} mean {v.mean() * tick / 1e3:7.3f} us   share {v.sum() / life.sum():.3f}")
 plife = P[:, 3] - P[:, 0]
 ok = plife > 0
+if (P[ok, 4] > 0).all():      # (builds that stamp the producers' prologue)
+    for name, a_, b_ in (("entry -> first halo loads issued", 0, 4), ("... -> first pass staged (its loads are back)", 4, 5), ("... -> first chunk staged", 5, 6), ("... -> first barrier passed", 6, 7)):
+        v = (P[ok, b_] - P[ok, a_])
+        print(f"  producers: {name:48s} mean {v.mean() * tick / 1e3:7.3f} us")
 print(f"producer waves: life {plife[ok].mean() * tick / 1e3:.2f} us; at barriers {P[ok, 1].sum() / plife[ok].sum():.3f}, staging (LDS writes + next loads issued) {P[ok, 2].sum() / plife[ok].sum():.3f}")
